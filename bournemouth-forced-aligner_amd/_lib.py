@@ -1,0 +1,92 @@
+"""ctypes binding of libbfa_hip.so (include/bfa.h).  Fails loudly when the library is missing:
+there is deliberately no fallback implementation."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbfa_hip.so")
+
+BFA_OK = 0
+BFA_ERR_INVALID_ARGUMENT, BFA_ERR_NO_DEVICE, BFA_ERR_LAUNCH = -1, -2, -3
+BFA_ERR_WORKSPACE_TOO_SMALL, BFA_ERR_UNSUPPORTED = -4, -5
+ITEM_OK, ITEM_TOO_SHORT, ITEM_BAD_TOKEN, ITEM_TOO_LARGE, ITEM_SEG_OVERFLOW = 0, 1, 2, 3, 4
+MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
+
+EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
+           "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
+           "bfa_postprocess", "bfa_log_softmax"]
+
+
+class BfaParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "blank_id", "silence_id", "silence_anchors", "ignore_noise", "truly_forced", "boost_targets",
+        "enforce_minimum", "simple", "max_blanks")] + [("reserved", ctypes.c_int32 * 3)]
+
+
+class BfaSegment(ctypes.Structure):
+    _fields_ = [("phoneme", ctypes.c_int32), ("start", ctypes.c_int32), ("end", ctypes.c_int32),
+                ("target_idx", ctypes.c_int32)]
+
+
+def build(force=False):
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src_dir]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"HIP extension {SO_PATH} is missing. Build it with `python __graft_entry__.py` (or "
+            f"`make -C {os.path.join(_HERE, 'csrc')}`). There is no CPU fallback for the alignment path.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    L.bfa_version.restype = ctypes.c_char_p
+    L.bfa_abi_version.restype = ctypes.c_int
+    L.bfa_create.argtypes = [ctypes.POINTER(vp), i32]
+    L.bfa_destroy.argtypes = [vp]
+    L.bfa_last_error.argtypes = [vp]
+    L.bfa_last_error.restype = ctypes.c_char_p
+    L.bfa_params_default.argtypes = [ctypes.POINTER(BfaParams), i32, i32]
+    L.bfa_params_default.restype = None
+    L.bfa_workspace_bytes.argtypes = [i32, i32, i32, i32, ctypes.POINTER(BfaParams)]
+    L.bfa_workspace_bytes.restype = sz
+    L.bfa_align_batch.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(BfaParams),
+                                  vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+    L.bfa_confidences.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]
+    L.bfa_postprocess.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]
+    L.bfa_log_softmax.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
+    _lib = L
+    return L
+
+
+_handles = {}
+
+
+def handle(device_index):
+    """One bfa handle per GPU per process."""
+    if device_index not in _handles:
+        h = ctypes.c_void_p()
+        rc = lib().bfa_create(ctypes.byref(h), int(device_index))
+        if rc != BFA_OK:
+            raise RuntimeError(f"bfa_create(device={device_index}) failed with status {rc} "
+                               f"(no GPU visible? this package has no CPU path)")
+        _handles[device_index] = h
+    return _handles[device_index]
+
+
+def check(rc, h, what):
+    if rc != BFA_OK:
+        msg = lib().bfa_last_error(h)
+        raise RuntimeError(f"{what} failed: status {rc}: {msg.decode() if msg else ''}")

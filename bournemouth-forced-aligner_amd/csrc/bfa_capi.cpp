@@ -1,0 +1,248 @@
+// bfa_capi.cpp -- the C-ABI of include/bfa.h on top of the gfx950 kernels in bfa_kernels.hip.
+// Host-side work here is argument checking and carving the caller's workspace; every per-utterance
+// decision (mode, stride, band, segmentation) is taken on the device, so a call never synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "bfa_types.hpp"
+
+extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream);
+extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
+extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
+                                      int C, void *stream);
+extern "C" int bfa_launch_postprocess(const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                                      const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count,
+                                      int extend, double th1, double th2, void *stream);
+
+struct bfa_context {
+    int device;
+    int num_cu;
+    std::string err;
+};
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carve {
+    size_t off = 0;
+    char *base;
+    explicit Carve(void *b) : base((char *)b) {}
+    template <typename T> T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+bool segmented_possible(const bfa_params *p) { return !p->simple && p->silence_anchors > 0 && p->silence_id >= 0; }
+
+// shape-only bounds shared by bfa_workspace_bytes and bfa_align_batch
+struct Layout {
+    int item_cap;
+    int64_t bp_per_utt; // dwords
+};
+
+Layout layout_for(int B, int Tmax, int Smax, const bfa_params *p)
+{
+    Layout l;
+    const bool seg = segmented_possible(p);
+    const int Lmax = 4 * (Smax > 0 ? Smax : 1) + 1;
+    const int nseg_max = seg ? (Smax + 3) : 0; // speech + silence pieces of one utterance
+    l.item_cap = B + (seg ? B * nseg_max : 0);
+    const int R = bfa::r_class_for_L(Lmax);
+    const int64_t quads = (Tmax + 3) / 4 + (seg ? 3 * (int64_t)(Smax / 2 + 2) : 0);
+    if (R > 0) l.bp_per_utt = quads * bfa::bp_words_for_R(R) * 64;
+    else l.bp_per_utt = quads * 4 * ((Lmax + 15) / 16);
+    return l;
+}
+
+size_t carve_all(Carve &c, int B, int Tmax, int Smax, const bfa_params *p, const Layout &l, bfa::AlignArgs *a,
+                 bool need_frames)
+{
+    const bool seg = segmented_possible(p);
+    auto items = c.take<bfa::Item>((size_t)l.item_cap);
+    auto counters = c.take<int32_t>(16);
+    auto umask = c.take<uint32_t>((size_t)B * bfa::MASK_WORDS);
+    auto uT = c.take<int32_t>((size_t)B);
+    auto uS = c.take<int32_t>((size_t)B);
+    auto umode = c.take<int32_t>((size_t)B);
+    auto anchor = c.take<uint8_t>(seg ? (size_t)B * Tmax : 1);
+    auto psil = c.take<float>(seg ? (size_t)B * Tmax : 1);
+    int32_t *fph = nullptr, *fidx = nullptr;
+    if (need_frames) {
+        fph = c.take<int32_t>((size_t)B * Tmax);
+        fidx = c.take<int32_t>((size_t)B * Tmax);
+    }
+    auto bp = c.take<uint32_t>((size_t)B * (size_t)l.bp_per_utt);
+    if (a) {
+        a->items = items; a->item_cap = l.item_cap; a->counters = counters; a->umask = umask; a->uT = uT; a->uS = uS;
+        a->umode = umode; a->anchor = anchor; a->psil = psil; a->bp = bp; a->bp_cap = (int64_t)B * l.bp_per_utt;
+        a->bp_per_utt = l.bp_per_utt;
+        if (need_frames) { a->frame_ph = fph; a->frame_idx = fidx; }
+    }
+    (void)Smax;
+    return align_up(c.off, 256);
+}
+
+int fail(bfa_handle h, int code, const char *msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *bfa_version(void) { return "bfa-hip 0.1.0 (gfx950)"; }
+int bfa_abi_version(void) { return BFA_ABI_VERSION; }
+
+void bfa_params_default(bfa_params *p, int blank_id, int silence_id)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->blank_id = blank_id;
+    p->silence_id = silence_id;
+    p->silence_anchors = 10;
+    p->ignore_noise = 1;
+    p->truly_forced = 1;
+    p->boost_targets = 1;
+    p->enforce_minimum = 1;
+    p->simple = 0;
+    p->max_blanks = 10;
+}
+
+int bfa_create(bfa_handle *out, int device)
+{
+    if (!out) return BFA_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BFA_ERR_NO_DEVICE; // no CPU fallback
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return BFA_ERR_NO_DEVICE;
+    }
+    if (device >= n) return BFA_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BFA_ERR_NO_DEVICE;
+    bfa_context *h = new (std::nothrow) bfa_context();
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    h->device = device;
+    h->num_cu = prop.multiProcessorCount;
+    *out = h;
+    return BFA_OK;
+}
+
+int bfa_destroy(bfa_handle h)
+{
+    delete h;
+    return BFA_OK;
+}
+
+const char *bfa_last_error(bfa_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p)
+{
+    if (B <= 0 || Tmax <= 0 || Smax <= 0 || !p) return 0;
+    (void)C;
+    const Layout l = layout_for(B, Tmax, Smax, p);
+    Carve c(nullptr);
+    return carve_all(c, B, Tmax, Smax, p, l, nullptr, true) + 256;
+}
+
+int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
+                    const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
+                    bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
+                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!logp || !tokens || !S_len || !params || !out_segs || !out_seg_count || !out_status || !workspace)
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (B <= 0 || Tmax <= 0 || Smax <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
+    if (C < 2 || C > bfa::MAX_C) return fail(h, BFA_ERR_UNSUPPORTED, "C must be in [2,128]");
+    if (params->blank_id < 0 || params->blank_id >= C)
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "Blank ID not set"); // forced_alignment.py:104-105
+    if (strideT < C) return fail(h, BFA_ERR_INVALID_ARGUMENT, "strideT < C");
+    if (C < 16 && params->boost_targets && !params->simple)
+        return fail(h, BFA_ERR_UNSUPPORTED, "boost_targets needs C >= 16 (vectorised softmax order)");
+    if ((out_frame_phoneme == nullptr) != (out_frame_idx == nullptr))
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "frame outputs must both be given or both be NULL");
+
+    const bool need_frames = (out_frame_phoneme == nullptr);
+    const Layout l = layout_for(B, Tmax, Smax, params);
+    bfa::AlignArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const uintptr_t basep = (uintptr_t)workspace;
+    const uintptr_t aligned = (basep + 255) & ~(uintptr_t)255;
+    Carve c((void *)aligned);
+    a.frame_ph = out_frame_phoneme;
+    a.frame_idx = out_frame_idx;
+    const size_t need = carve_all(c, B, Tmax, Smax, params, l, &a, need_frames) + (aligned - basep);
+    if (need > workspace_bytes) return fail(h, BFA_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
+
+    a.logp = logp; a.strideB = strideB; a.strideT = strideT;
+    a.B = B; a.Tmax = Tmax; a.C = C; a.Smax = Smax;
+    a.T_len = T_len; a.tokens = tokens; a.S_len = S_len;
+    a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = params->silence_anchors;
+    a.p.ignore_noise = params->ignore_noise; a.p.truly_forced = params->truly_forced;
+    a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = params->simple;
+    a.p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
+    a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
+
+    int grid = l.item_cap < 65536 ? l.item_cap : 65536;
+    const int rc = bfa_launch_align(&a, grid, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_confidences(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *T_rows, const bfa_segment *segs, int seg_cap, const int32_t *seg_count,
+                    float *out_conf, int32_t *out_item_status, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!logp || !segs || !seg_count || !out_conf) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
+    bfa::ConfArgs a;
+    a.logp = logp; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.T_rows = T_rows;
+    a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.conf = out_conf; a.status = out_item_status;
+    const int rc = bfa_launch_conf(&a, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int extend,
+                    int boundary_softness, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!logp || !S_len || !segs || !seg_count) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
+    if (seg_cap > 4096) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 4096 in bfa_postprocess");
+    // core.py:699-701 : python `10.0 ** -n` is libm pow on doubles
+    const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)boundary_softness);
+    const int rc = bfa_launch_postprocess(logp, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, extend,
+                                          th1, th2, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
+                    int C, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!logits || !out || rows < 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");
+    if (C < 16 || C > bfa::MAX_C) return fail(h, BFA_ERR_UNSUPPORTED, "C must be in [16,128]");
+    if (rows == 0) return BFA_OK;
+    const int rc = bfa_launch_log_softmax(logits, ld_in, out, ld_out, rows, C, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+} // extern "C"

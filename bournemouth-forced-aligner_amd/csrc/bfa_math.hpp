@@ -1,0 +1,120 @@
+// bfa_math.hpp -- float32 numerics that must agree bit-for-bit with the reference's host library.
+//
+// The reference normalises with torch.nn.functional.log_softmax on a CPU tensor
+// (forced_alignment.py:54,560).  On the AVX512 dispatch of torch 2.10 that is: row max, a
+// Sleef-u10 expf of (x - max) accumulated in sixteen lane sums (tail columns into the low lanes),
+// an xor-butterfly 8/4/2/1 over the sixteen sums, a Sleef-u10 logf of the total and
+// out = (x - max) - log(sum).  The two functions below are written from Sleef's published
+// algorithm (FMA build) with explicit __builtin_fmaf so that, compiled with -ffp-contract=off,
+// every operation is a single IEEE rounding on the GPU exactly as on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace bfa {
+
+__device__ __forceinline__ float as_f(int i) { return __builtin_bit_cast(float, i); }
+__device__ __forceinline__ int as_i(float f) { return __builtin_bit_cast(int, f); }
+
+// 2^q for q in the normal exponent range
+__device__ __forceinline__ float pow2i(int q) { return as_f((q + 0x7f) << 23); }
+
+__device__ __forceinline__ float expf_u10(float d)
+{
+    const int q = (int)__builtin_rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const float qf = (float)q;
+    float s = __builtin_fmaf(qf, -0.693145751953125f, d);
+    s = __builtin_fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = 1.0f + __builtin_fmaf(s * s, u, s);
+    u = (u * pow2i(q >> 1)) * pow2i(q - (q >> 1));
+    if (d < -104.0f) u = 0.0f;
+    if (d > 100.0f) u = __builtin_inff();
+    return u;
+}
+
+struct f2 { float x, y; };
+__device__ __forceinline__ f2 df_mul_f(f2 a, float b)
+{
+    f2 r; r.x = a.x * b; r.y = __builtin_fmaf(a.y, b, __builtin_fmaf(a.x, b, -r.x)); return r;
+}
+__device__ __forceinline__ f2 df_add2_ff(float a, float b)
+{
+    f2 r; r.x = a + b; const float v = r.x - a; r.y = (a - (r.x - v)) + (b - v); return r;
+}
+__device__ __forceinline__ f2 df_div(f2 n, f2 d)
+{
+    const float t = 1.0f / d.x; // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the hipcc default)
+    f2 q; q.x = n.x * t;
+    const float u = __builtin_fmaf(t, n.x, -q.x);
+    const float w = __builtin_fmaf(-d.y, t, __builtin_fmaf(-d.x, t, 1.0f));
+    q.y = __builtin_fmaf(q.x, w, __builtin_fmaf(n.y, t, u));
+    return q;
+}
+__device__ __forceinline__ f2 df_add_22(f2 a, f2 b)
+{
+    f2 r; r.x = a.x + b.x; r.y = (((a.x - r.x) + b.x) + a.y) + b.y; return r;
+}
+__device__ __forceinline__ f2 df_add_2f(f2 a, float b)
+{
+    f2 r; r.x = a.x + b; r.y = ((a.x - r.x) + b) + a.y; return r;
+}
+
+// positive normal arguments only: the softmax denominator lies in [1, C]
+__device__ __forceinline__ float logf_u10(float d)
+{
+    const float de = d * (1.0f / 0.75f);
+    const float e = (float)(((as_i(de) >> 23) & 0xff) - 127);
+    float m = as_f((as_i(d) & 0x007fffff) | 0x3f800000);
+    if (m >= 1.5f) m *= 0.5f;
+    const f2 ln2 = {0.69314718246459960938f, -1.904654323148236017e-09f};
+    f2 s = df_mul_f(ln2, e);
+    const f2 x = df_div(df_add2_ff(-1.0f, m), df_add2_ff(1.0f, m));
+    const float x2 = x.x * x.x;
+    float t = 0.3027294874e+0f;
+    t = __builtin_fmaf(t, x2, 0.3996108174e+0f);
+    t = __builtin_fmaf(t, x2, 0.6666694880e+0f);
+    const f2 xs = {x.x * 2.0f, x.y * 2.0f};
+    s = df_add_22(s, xs);
+    s = df_add_2f(s, x2 * x.x * t);
+    return s.x + s.y;
+}
+
+// ---- cross-lane helpers (wave64) -------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float v)
+{
+    return as_f(__builtin_amdgcn_update_dpp(as_i(old), as_i(v), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_WAVE_SHR1 = 0x138; // lane l <- lane l-1 across the whole wave64, lane 0 keeps `old`
+constexpr int DPP_ROW_ROR8 = 0x128;  // rotate within each 16-lane row
+constexpr int DPP_ROW_ROR4 = 0x124;
+constexpr int DPP_ROW_ROR2 = 0x122;
+constexpr int DPP_ROW_ROR1 = 0x121;
+
+// sum over the sixteen lanes of a DPP row in torch's butterfly order: v += v[j^8]; ^4; ^2; ^1.
+// After each step the vector is periodic, so rotate-by-sh reads the same value as xor-sh.
+__device__ __forceinline__ float row16_butterfly_add(float v)
+{
+    v = v + dpp_mov<DPP_ROW_ROR8>(0.0f, v);
+    v = v + dpp_mov<DPP_ROW_ROR4>(0.0f, v);
+    v = v + dpp_mov<DPP_ROW_ROR2>(0.0f, v);
+    v = v + dpp_mov<DPP_ROW_ROR1>(0.0f, v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = __builtin_fmaxf(v, dpp_mov<DPP_ROW_ROR8>(v, v));
+    v = __builtin_fmaxf(v, dpp_mov<DPP_ROW_ROR4>(v, v));
+    v = __builtin_fmaxf(v, dpp_mov<DPP_ROW_ROR2>(v, v));
+    v = __builtin_fmaxf(v, dpp_mov<DPP_ROW_ROR1>(v, v));
+    return v;
+}
+
+} // namespace bfa

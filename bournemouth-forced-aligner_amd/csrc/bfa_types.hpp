@@ -1,0 +1,108 @@
+// bfa_types.hpp -- device-side records shared by the kernels and the C-ABI layer.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/bfa.h"
+
+namespace bfa {
+
+constexpr float NEG = -1000.0f;                   // forced_alignment.py:23 `_neg_inf` (finite on purpose)
+constexpr float MIN_LOGP = -18.420680999755859375f; // float32 log(1e-8), forced_alignment.py:70
+constexpr int MAX_C = 128;                        // target-column mask is 4 x u32
+constexpr int MASK_WORDS = MAX_C / 32;
+constexpr int MAX_R = 16;                         // CTC states per lane in the wave kernel -> L <= 1024
+constexpr int MAX_L_BIG = 16384;                  // workgroup fallback kernel
+
+// what one DP / fill work item covers
+enum ItemKind : int32_t {
+    ITEM_NONE = 0,
+    ITEM_DP = 1,          // banded Viterbi over rows [row0,row0+Ts), writes frames [out0,out0+nout)
+    ITEM_FILL_BLANK = 2,  // blank / -1
+    ITEM_FILL_PROP = 3,   // proportional assignment forced_alignment.py:170-172
+    ITEM_FILL_SIL = 4     // silence segment, forced_alignment.py:382-397
+};
+
+struct Item {
+    int32_t kind;
+    int32_t utt;       // utterance index b
+    int32_t row0;      // first posterior row of the DP (padded_start)
+    int32_t Ts;        // rows in the DP
+    int32_t tok0;      // first target index covered
+    int32_t nt;        // number of targets covered
+    int32_t stride;    // CTC expansion stride 1..4
+    int32_t L;         // stride*nt+1
+    int32_t bw;        // Sakoe-Chiba half width, 0 = no band
+    int32_t out0;      // first output frame (audio_start)
+    int32_t nout;      // output frames
+    int32_t pad_left;  // out0 - row0
+    int32_t final_state;
+    int32_t anchored;  // 1 = some rows of this DP carry silence-anchor counts
+    int64_t bp_off;    // dword offset of this item's backpointer block in the workspace
+};
+
+struct DevParams {
+    int32_t blank, sil, anchors, ignore_noise, truly_forced, boost, enforce, simple, max_blanks;
+};
+
+// everything the kernels of one bfa_align_batch call need; passed by value
+struct AlignArgs {
+    const float *logp;
+    int64_t strideB, strideT;
+    int32_t B, Tmax, C, Smax;
+    const int32_t *T_len, *tokens, *S_len;
+    DevParams p;
+    int32_t *frame_ph, *frame_idx;
+    bfa_segment *segs;
+    int32_t seg_cap;
+    int32_t *seg_count, *status, *mode;
+    // workspace carve
+    Item *items;
+    int32_t item_cap;
+    int32_t *counters;      // [0] = number of items, [1] = bp dwords used (lo), [2] spare
+    uint32_t *umask;        // [B][MASK_WORDS] target-column bit mask
+    int32_t *uT, *uS;       // [B] clamped lengths
+    int32_t *umode;         // [B] decode mode (negative while the segmented planner is undecided)
+    uint8_t *anchor;        // [B][Tmax] silence-anchor counts (segmented mode)
+    float *psil;            // [B][Tmax] exp(m[:,SIL]) (segmented mode)
+    uint32_t *bp;           // backpointer pool
+    int64_t bp_cap;         // dwords
+    int64_t bp_per_utt;     // dwords reserved for the one-DP-per-utterance case
+};
+
+struct ConfArgs {
+    const float *logp;
+    int64_t strideB, strideT;
+    int32_t B, Tmax, C;
+    const int32_t *T_rows;
+    const bfa_segment *segs;
+    int32_t seg_cap;
+    const int32_t *seg_count;
+    float *conf;
+    int32_t *status;
+};
+
+__host__ __device__ inline int r_class_for_L(int L)
+{
+    const int r = (L + 63) / 64;
+    if (r <= 1) return 1;
+    if (r <= 2) return 2;
+    if (r <= 3) return 3;
+    if (r <= 4) return 4;
+    if (r <= 6) return 6;
+    if (r <= 8) return 8;
+    if (r <= 12) return 12;
+    if (r <= 16) return 16;
+    return 0; // too long for the wave kernel
+}
+__host__ __device__ inline int bp_words_for_R(int R) { return (R + 3) / 4; } // dwords per lane per 4 frames
+
+// dwords of backpointer storage for one DP of Ts rows and path length L
+__host__ __device__ inline int64_t bp_dwords(int Ts, int L)
+{
+    const int R = r_class_for_L(L);
+    const int64_t quads = (Ts + 3) / 4;
+    if (R > 0) return quads * bp_words_for_R(R) * 64;
+    return (int64_t)Ts * ((L + 15) / 16); // big-L kernel: 2 bits per state, row-major
+}
+
+} // namespace bfa

@@ -1,0 +1,263 @@
+"""Host-side mirror of bournemouth_aligner/forced_alignment.py (reference lines cited per method).
+
+Same class names, constructor arguments, method names, return types and error behaviour as the
+reference's `ViterbiDecoder` / `AlignmentUtils`; the work itself runs in the gfx950 kernels behind
+the C-ABI of include/bfa.h.  Posteriors stay device-resident: `log_probs` is expected to be a
+float32 tensor on the GPU (a CPU tensor is uploaded, that is plumbing, not a fallback -- without a
+GPU every entry point raises).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _device_of(t):
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("bournemouth-forced-aligner_amd needs an AMD GPU (HIP): no device is visible and "
+                           "there is no CPU implementation of the alignment path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _as_i32(x, device, n=None):
+    if x is None:
+        return None
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.asarray(x))
+    return x.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+
+
+class _Workspace:
+    """Caller-owned scratch for bfa_align_batch, cached per shape."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class AlignmentResult:
+    """Device-resident result of one batch (no host synchronisation has happened yet)."""
+
+    def __init__(self, segs, seg_count, status, mode, frame_ph, frame_idx, T_len, S_len):
+        self.segs = segs            # int32 [B, seg_cap, 4]  (phoneme, start, end, target_idx)
+        self.seg_count = seg_count  # int32 [B]
+        self.status = status        # int32 [B]  BFA_ITEM_*
+        self.mode = mode            # int32 [B]  BFA_MODE_*
+        self.frame_phonemes = frame_ph    # int32 [B, Tmax]
+        self.frame_phonemes_idx = frame_idx
+        self.T_len = T_len
+        self.S_len = S_len
+
+    def raise_for_status(self):
+        """Reproduce the reference's exceptions (they abort the whole call)."""
+        st = self.status.cpu().numpy()
+        if (st == _lib.ITEM_OK).all():
+            return
+        T = self.T_len.cpu().numpy() if self.T_len is not None else None
+        S = self.S_len.cpu().numpy()
+        for b in range(st.shape[0]):
+            if st[b] == _lib.ITEM_TOO_SHORT:  # forced_alignment.py:161-165
+                nf = int(T[b]) if T is not None else self.frame_phonemes.shape[1]
+                raise ValueError(
+                    f"Audio too short to align: {int(S[b])} phonemes cannot be fit into "
+                    f"{nf} frames (need at least 1 frame per phoneme).")
+            if st[b] == _lib.ITEM_BAD_TOKEN:
+                raise IndexError(f"target phoneme id out of range for item {b} (index out of range in log_probs)")
+            if st[b] == _lib.ITEM_TOO_LARGE:
+                raise RuntimeError(f"item {b}: CTC path longer than this build supports")
+            if st[b] == _lib.ITEM_SEG_OVERFLOW:
+                raise RuntimeError(f"item {b}: more aligned runs than seg_cap")
+
+    def to_lists(self):
+        """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871)."""
+        cnt = self.seg_count.cpu().numpy()
+        segs = self.segs.cpu().numpy()
+        out = []
+        for b in range(cnt.shape[0]):
+            rows = segs[b, :cnt[b]].tolist()
+            out.append([tuple(r) for r in rows])
+        return out
+
+
+class ViterbiDecoder:
+    """Mirror of forced_alignment.py:11-834 (constructor :16-23)."""
+
+    def __init__(self, blank_id, silence_id, silence_anchors=3, min_phoneme_prob=1e-8, ignore_noise=True,
+                 truly_forced=False):
+        self.blank_id = blank_id
+        self.silence_id = silence_id
+        self.silence_anchors = silence_anchors
+        self.min_phoneme_prob = min_phoneme_prob  # the kernels implement the reference default 1e-8 only
+        self.ignore_noise = ignore_noise
+        self.truly_forced = truly_forced
+        self._neg_inf = -1000.0
+        self._ws = _Workspace()
+
+    def set_blank_id(self, blank_id):
+        """forced_alignment.py:25-27"""
+        self.blank_id = blank_id
+
+    # ---- parameter block for the C-ABI
+    def _params(self, boost_targets, enforce_minimum, anchor_pauses, simple=False, max_blanks=10):
+        if self.blank_id is None:
+            raise ValueError("Blank ID not set. Call set_blank_id first.")  # forced_alignment.py:104-105
+        if abs(self.min_phoneme_prob - 1e-8) > 0:
+            raise NotImplementedError("min_phoneme_prob other than the reference default 1e-8")
+        p = _lib.BfaParams()
+        p.blank_id = int(self.blank_id)
+        p.silence_id = -1 if self.silence_id is None else int(self.silence_id)
+        p.silence_anchors = int(self.silence_anchors) if anchor_pauses else 0
+        p.ignore_noise = int(bool(self.ignore_noise))
+        p.truly_forced = int(bool(self.truly_forced))
+        p.boost_targets = int(bool(boost_targets))
+        p.enforce_minimum = int(bool(enforce_minimum))
+        p.simple = int(bool(simple))
+        p.max_blanks = int(max_blanks)
+        return p
+
+    def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
+                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10):
+        """Whole-batch device call (bfa_align_batch).  Returns an AlignmentResult of device tensors; nothing
+        is synchronised or copied to the host here."""
+        if log_probs.dim() != 3:
+            raise ValueError("log_probs must be [B, T, C]")
+        dev = _device_of(log_probs)
+        lp = log_probs.to(device=dev, dtype=torch.float32)
+        if lp.stride(2) != 1:
+            lp = lp.contiguous()
+        B, Tmax, C = lp.shape
+        toks = _as_i32(true_seqs, dev)
+        if toks.dim() == 1:
+            toks = toks.unsqueeze(0)
+        Smax = max(1, toks.shape[1])
+        if toks.shape[1] == 0:
+            toks = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+        S_len = _as_i32(true_seqs_lens, dev)
+        T_len = _as_i32(pred_lens, dev)
+        params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
+        if seg_cap is None:
+            seg_cap = Smax + 2 if self.ignore_noise else Tmax + 1
+        L = _lib.lib()
+        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+        nbytes = L.bfa_workspace_bytes(B, Tmax, Smax, C, ctypes.byref(params))
+        ws = self._ws.get(nbytes, dev)
+        segs = torch.empty((B, seg_cap, 4), dtype=torch.int32, device=dev)
+        seg_count = torch.empty((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        mode = torch.empty((B,), dtype=torch.int32, device=dev)
+        fph = torch.empty((B, Tmax), dtype=torch.int32, device=dev)
+        fidx = torch.empty((B, Tmax), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = L.bfa_align_batch(h, lp.data_ptr(), lp.stride(0), lp.stride(1), B, Tmax, C,
+                                   T_len.data_ptr() if T_len is not None else None, toks.data_ptr(),
+                                   S_len.data_ptr(), Smax, ctypes.byref(params), fph.data_ptr(), fidx.data_ptr(),
+                                   segs.data_ptr(), seg_cap, seg_count.data_ptr(), status.data_ptr(),
+                                   mode.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        _lib.check(rc, h, "bfa_align_batch")
+        res = AlignmentResult(segs, seg_count, status, mode, fph, fidx, T_len, S_len)
+        res._keepalive = (lp, toks, ws)
+        return res
+
+    def decode_with_forced_alignment(self, log_probs, true_sequence, return_scores=False, boost_targets=True,
+                                     enforce_minimum=True, anchor_pauses=True, debug=False):
+        """forced_alignment.py:87-199 for one utterance: log_probs [T, C], true_sequence [S].
+        Returns (frame_phonemes[T], frame_phonemes_idx[T], score-or-None) as int64 tensors."""
+        if self.blank_id is None:
+            raise ValueError("Blank ID not set. Call set_blank_id first.")
+        T = log_probs.shape[0]
+        S = int(true_sequence.shape[0])
+        dev = _device_of(log_probs)
+        if S == 0:  # :112-118
+            fp = torch.full((T,), int(self.blank_id), dtype=torch.long, device=dev)
+            fi = torch.full((T,), -1, dtype=torch.long, device=dev)
+            score = log_probs[:, self.blank_id].sum() if return_scores else None
+            return fp, fi, score
+        res = self.align_batch(log_probs.unsqueeze(0), true_sequence.reshape(1, -1), [T], [S],
+                               boost_targets=boost_targets, enforce_minimum=enforce_minimum,
+                               anchor_pauses=anchor_pauses and self.silence_id is not None, seg_cap=max(T, 1))
+        res.raise_for_status()
+        fp = res.frame_phonemes[0, :T].long()
+        fi = res.frame_phonemes_idx[0, :T].long()
+        score = self._calculate_alignment_score(log_probs, fp) if return_scores else None
+        return fp, fi, score
+
+    def _calculate_alignment_score(self, log_probs, frame_phonemes):
+        """forced_alignment.py:767-773 (python-float accumulation == float64 sum)."""
+        lp = log_probs.to(frame_phonemes.device)
+        ok = frame_phonemes < lp.shape[1]
+        idx = torch.where(ok, frame_phonemes, torch.zeros_like(frame_phonemes))
+        vals = lp[torch.arange(lp.shape[0], device=lp.device), idx].double()
+        return float((vals * ok.double()).sum().item())
+
+    def assort_frames(self, frame_phonemes, frame_phonemes_idx, max_blanks=10):
+        """forced_alignment.py:777-834 as a standalone call (host arithmetic on integer arrays; the batch path
+        runs the same rule in the k_assort kernel)."""
+        if len(frame_phonemes) == 0:
+            return []
+        ph = np.asarray(frame_phonemes.cpu() if isinstance(frame_phonemes, torch.Tensor) else frame_phonemes)
+        ix = np.asarray(frame_phonemes_idx.cpu() if isinstance(frame_phonemes_idx, torch.Tensor) else frame_phonemes_idx)
+        change = np.ones(len(ph), bool)
+        change[1:] = (ph[1:] != ph[:-1]) | (ix[1:] != ix[:-1])
+        starts = np.flatnonzero(change)
+        ends = np.append(starts[1:], len(ph))
+        out = []
+        for s, e in zip(starts.tolist(), ends.tolist()):
+            p, i = int(ph[s]), int(ix[s])
+            if p == self.blank_id:
+                if (not self.ignore_noise) and (e - s) > max_blanks:
+                    out.append((p, s, e, i))
+            else:
+                out.append((p, s, e, i))
+        return out
+
+
+class AlignmentUtils:
+    """Mirror of forced_alignment.py:836-987."""
+
+    def __init__(self, blank_id, silence_id, silence_anchors=10, ignore_noise=True, truly_forced=True):
+        self.blank_id = blank_id
+        self.silence_id = silence_id
+        self.silence_anchors = silence_anchors
+        self.truly_forced = truly_forced
+        self.viterbi_decoder = ViterbiDecoder(blank_id, silence_id, silence_anchors=self.silence_anchors,
+                                              ignore_noise=ignore_noise, truly_forced=self.truly_forced)
+
+    def decode_alignments_device(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True,
+                                 enforce_minimum=True, seg_cap=None):
+        """decode_alignments without the host round trip: returns an AlignmentResult (device tensors)."""
+        return self.viterbi_decoder.align_batch(log_probs, true_seqs, pred_lens, true_seqs_lens,
+                                                boost_targets=boost_targets, enforce_minimum=enforce_minimum,
+                                                anchor_pauses=self.silence_anchors > 0, seg_cap=seg_cap)
+
+    def decode_alignments(self, log_probs, true_seqs=None, pred_lens=None, true_seqs_lens=None,
+                          forced_alignment=True, boost_targets=True, enforce_minimum=True, debug=False):
+        """forced_alignment.py:856-910.  Returns list[B] of list[(phoneme_id, start, end, target_seq_idx)]."""
+        if not forced_alignment:
+            raise NotImplementedError("free decoding (forced_alignment=False) is outside the accelerated path")
+        if (true_seqs is None) or (true_seqs_lens is None):
+            raise ValueError("Phoneme sequences and lengths required for forced alignment")  # :878-879
+        res = self.decode_alignments_device(log_probs, true_seqs, pred_lens, true_seqs_lens,
+                                            boost_targets=boost_targets, enforce_minimum=enforce_minimum)
+        res.raise_for_status()
+        return res.to_lists()
+
+    def decode_alignments_simple(self, log_probs, true_seqs, pred_lens=None, true_seqs_lens=None):
+        """forced_alignment.py:932-987 (no boost / floor / anchoring; float32 band arithmetic)."""
+        B, Tmax = log_probs.shape[0], log_probs.shape[1]
+        if pred_lens is None:
+            pred_lens = [Tmax] * B
+        if true_seqs_lens is None:
+            true_seqs_lens = [true_seqs.shape[1]] * B
+        res = self.viterbi_decoder.align_batch(log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=False,
+                                               enforce_minimum=False, anchor_pauses=False, simple=True)
+        res.raise_for_status()
+        return res.to_lists()

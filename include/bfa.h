@@ -1,0 +1,148 @@
+/*
+ * include/bfa.h -- C-ABI of the MI355X-native forced-alignment core (libbfa_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of tabahi/bournemouth-forced-aligner: the Viterbi forced
+ * alignment over the [T x C] phoneme-posterior matrix and the per-phoneme confidence pass.
+ * The reference has no FFI for this path -- it is a Python class boundary:
+ *
+ *   bournemouth_aligner/core.py:23       from .forced_alignment import AlignmentUtils
+ *   bournemouth_aligner/core.py:252-257  _setup_decoders() builds alignment_utils_p / _g
+ *   bournemouth_aligner/core.py:902-922  .decode_alignments(...)          -> bfa_align_batch
+ *   bournemouth_aligner/core.py:1028     .decode_alignments_simple(...)   -> bfa_align_batch (params.simple=1)
+ *   bournemouth_aligner/core.py:936-937  utils._calculate_confidences     -> bfa_confidences
+ *   bournemouth_aligner/core.py:925-931  ensure_target_coverage (default) +
+ *                                        extend_soft_boundaries_func      -> bfa_postprocess
+ *
+ * so these entry points are what a ctypes binding inside the reference's forced_alignment.py
+ * would call (INTEGRATION.md shows that stub).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - the caller owns every buffer, including outputs and the workspace (size it with
+ *     bfa_workspace_bytes); the library allocates nothing per call and never frees caller memory;
+ *   - calls are stream-ordered and return without synchronising; buffers must stay alive until
+ *     the stream has been synchronised;
+ *   - return value: BFA_OK or a negative bfa_status for call-level failures (bad argument,
+ *     launch failure).  Per-utterance outcomes go to out_status[B] (see BFA_ITEM_*);
+ *   - one handle per GPU per host thread; no hidden global state.
+ */
+#ifndef BFA_H
+#define BFA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFA_ABI_VERSION 1
+
+typedef struct bfa_context *bfa_handle;
+
+typedef enum {
+    BFA_OK = 0,
+    BFA_ERR_INVALID_ARGUMENT = -1,
+    BFA_ERR_NO_DEVICE = -2,
+    BFA_ERR_LAUNCH = -3,
+    BFA_ERR_WORKSPACE_TOO_SMALL = -4,
+    BFA_ERR_UNSUPPORTED = -5
+} bfa_status;
+
+/* per-utterance status written to out_status[b] */
+#define BFA_ITEM_OK 0
+#define BFA_ITEM_TOO_SHORT 1   /* T < S : reference raises ValueError("Audio too short to align ...")
+                                  (forced_alignment.py:161-165) and aborts the whole call */
+#define BFA_ITEM_BAD_TOKEN 2   /* token id outside [0,C) : reference raises IndexError */
+#define BFA_ITEM_TOO_LARGE 3   /* CTC path longer than this build supports */
+#define BFA_ITEM_SEG_OVERFLOW 4 /* more runs than seg_cap: frame outputs are valid, segments truncated */
+
+/* per-utterance decode mode written to out_mode[b] */
+#define BFA_MODE_EMPTY 0        /* S == 0 -> no segments (forced_alignment.py:894-897) */
+#define BFA_MODE_SEGMENTED 1    /* silence-anchored segmented Viterbi (forced_alignment.py:268-469) */
+#define BFA_MODE_STANDARD 2     /* one banded Viterbi (forced_alignment.py:153-193) */
+#define BFA_MODE_PROPORTIONAL 3 /* S >= T-? proportional assignment, no DP (forced_alignment.py:166-176) */
+
+/* AlignmentUtils(...) constructor fields + decode_alignments(...) flags
+ * (forced_alignment.py:841-853, 856-858) */
+typedef struct {
+    int32_t blank_id;        /* CTC blank ("noise"): 66 for the ph66 head, 16 for the group head */
+    int32_t silence_id;      /* SIL: 0 ; negative = None */
+    int32_t silence_anchors; /* default 10 ; 0 disables the segmented mode */
+    int32_t ignore_noise;    /* default 1 */
+    int32_t truly_forced;    /* default 1 (enforce_all_targets) */
+    int32_t boost_targets;   /* default 1 : +5.0 on target columns, then log_softmax */
+    int32_t enforce_minimum; /* default 1 : floor target columns at log(1e-8) */
+    int32_t simple;          /* 1 = decode_alignments_simple semantics (forced_alignment.py:932-987) */
+    int32_t max_blanks;      /* assort_frames(max_blanks=10) */
+    int32_t reserved[3];
+} bfa_params;
+
+/* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),
+ * end exclusive (forced_alignment.py:827,831) */
+typedef struct {
+    int32_t phoneme;
+    int32_t start;
+    int32_t end;
+    int32_t target_idx;
+} bfa_segment;
+
+const char *bfa_version(void);
+int bfa_abi_version(void);
+
+/* device < 0 : current HIP device.  Fails with BFA_ERR_NO_DEVICE when no GPU is present --
+ * there is no CPU fallback behind this ABI. */
+int bfa_create(bfa_handle *out, int device);
+int bfa_destroy(bfa_handle h);
+const char *bfa_last_error(bfa_handle h);
+void bfa_params_default(bfa_params *p, int blank_id, int silence_id);
+
+/* bytes of device scratch bfa_align_batch needs for these shapes (shape-only upper bound, so no
+ * host knowledge of the per-utterance lengths is required) */
+size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p);
+
+/*
+ * AlignmentUtils.decode_alignments / decode_alignments_simple for a whole batch.
+ *   logp        [B,Tmax,C] float32, element (b,t,c) at logp[b*strideB + t*strideT + c]
+ *   T_len       [B] int32 pred_lens (clamped to Tmax like the reference's slicing), NULL = Tmax
+ *   tokens      [B,Smax] int32 target ids (padding beyond S_len[b] is ignored)
+ *   S_len       [B] int32 true_seqs_lens
+ * outputs (any of frame/mode pointers may be NULL)
+ *   out_frame_phoneme / out_frame_idx  [B,Tmax] int32 framewise assignment (blank / -1 beyond T_len)
+ *   out_segs    [B,seg_cap] bfa_segment ; out_seg_count [B] ; out_status [B] ; out_mode [B]
+ */
+int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
+                    const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
+                    bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
+                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * utils._calculate_confidences (utils.py:70-113) for a whole batch, including the reference's
+ * in-place aliasing of probs[start, phoneme].  logp is the ORIGINAL (un-boosted) matrix; T_rows[b]
+ * is log_probs.shape[0] of item b as the reference passes it (the padded Tmax, core.py:936).
+ *   segs [B,seg_cap] ; seg_count [B] ; out_conf [B,seg_cap] float32 ;
+ *   out_item_status [B] (BFA_ITEM_BAD_TOKEN where the reference would raise IndexError)
+ */
+int bfa_confidences(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *T_rows, const bfa_segment *segs, int seg_cap, const int32_t *seg_count,
+                    float *out_conf, int32_t *out_item_status, void *stream);
+
+/*
+ * Post-DP boundary stages of extract_timestamps_from_segment_batch (core.py:925-931), in place on
+ * segs/seg_count: ensure_target_coverage with ensure_completeness=False (drop target_idx -1 / >= S,
+ * stable sort by start; core.py:488-513,660) then, if extend != 0, extend_soft_boundaries_func
+ * (core.py:682-809) over the padded Tmax rows.
+ */
+int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int extend,
+                    int boundary_softness, void *stream);
+
+/* F.log_softmax(dim=-1) of raw logits [rows,C] (core.py:898-899), torch-CPU-exact numerics */
+int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
+                    int C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFA_H */

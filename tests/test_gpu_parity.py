@@ -1,0 +1,144 @@
+"""-m gpu : parity of the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+Integer outputs (framewise states, boundaries, target indices) must be bit-exact; confidences are
+compared bit-exact as well (both sides use the same restated float32 exp), with the north-star
+tolerance 1e-4 as the hard bound."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk_batch(rng, n, C, Tr, Sr, **kw):
+    blank = C - 1
+    lps, toks = [], []
+    for _ in range(n):
+        T = int(rng.integers(*Tr))
+        S = int(rng.integers(Sr[0], max(Sr[0] + 1, min(Sr[1], T))))
+        lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, **kw)
+        lps.append(lp)
+        toks.append(tk)
+    return cases.pad_batch(lps, toks, C, blank)
+
+
+def _run_both(ora, dev, lp, tk, T_len, S_len, C, anchors=10, ign=True, tf=True, boost=True, enf=True, simple=False):
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    blank = C - 1
+    au = AlignmentUtils(blank, 0, silence_anchors=anchors, ignore_noise=ign, truly_forced=tf)
+    lpd = torch.from_numpy(lp).to(dev)
+    res = au.viterbi_decoder.align_batch(lpd, torch.from_numpy(tk), T_len, S_len, boost_targets=boost,
+                                         enforce_minimum=enf, anchor_pauses=anchors > 0, simple=simple,
+                                         seg_cap=lp.shape[1] + 1)
+    torch.cuda.synchronize()
+    prm = ora.make_params(blank, 0, anchors, ign, tf, boost, enf)
+    exp = ora.decode_alignments(lp, tk, T_len, S_len, prm, simple=simple)
+    return res, exp
+
+
+def _compare(res, exp, T_len):
+    st = res.status.cpu().numpy()
+    np.testing.assert_array_equal(st, exp["status"])
+    cnt = res.seg_count.cpu().numpy()
+    segs = res.segs.cpu().numpy()
+    fph = res.frame_phonemes.cpu().numpy()
+    fidx = res.frame_phonemes_idx.cpu().numpy()
+    for b in range(len(st)):
+        if st[b] != 0:
+            continue
+        T = int(T_len[b])
+        np.testing.assert_array_equal(fph[b, :T], exp["frame_ph"][b, :T], err_msg=f"frame phonemes item {b}")
+        np.testing.assert_array_equal(fidx[b, :T], exp["frame_idx"][b, :T], err_msg=f"frame idx item {b}")
+        assert cnt[b] == exp["seg_count"][b], f"segment count item {b}"
+        np.testing.assert_array_equal(segs[b, :cnt[b]], exp["seg"][b, :cnt[b]], err_msg=f"segments item {b}")
+    md = res.mode.cpu().numpy()
+    ok = st == 0
+    np.testing.assert_array_equal(md[ok], exp["mode"][ok])
+
+
+def test_log_softmax_bit_exact(ora, gpu_device):
+    from bournemouth_forced_aligner_amd import log_softmax
+    rng = np.random.default_rng(11)
+    for C in (67, 17, 16, 33, 128):
+        x = (rng.normal(0, 3, size=(1531, C))).astype(np.float32)
+        x[:, rng.integers(0, C)] += 9
+        got = log_softmax(torch.from_numpy(x).to(gpu_device)).cpu().numpy()
+        exp = ora.log_softmax_rows(x)
+        assert (got.view(np.int32) == exp.view(np.int32)).all(), f"C={C}"
+
+
+@pytest.mark.parametrize("C", [67, 17])
+@pytest.mark.parametrize("peak", [9.0, 2.0, 0.5])
+def test_standard_mode_parity(ora, gpu_device, C, peak):
+    rng = np.random.default_rng(100 + C + int(peak * 10))
+    lp, tk, T_len, S_len = _mk_batch(rng, 48, C, (8, 420), (1, 90), peak=peak, sigma=1.0, repeat_rate=0.1)
+    for tf in (True, False):
+        res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=0, tf=tf)
+        _compare(res, exp, T_len)
+
+
+def test_ignore_noise_false_and_given_emissions(ora, gpu_device):
+    rng = np.random.default_rng(5)
+    lp, tk, T_len, S_len = _mk_batch(rng, 32, 67, (30, 300), (1, 40), peak=6.0)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0, ign=False, boost=False, enf=False)
+    _compare(res, exp, T_len)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0, ign=False, boost=False, enf=True)
+    _compare(res, exp, T_len)
+
+
+def test_short_audio_modes(ora, gpu_device):
+    """stride 3/2/1, proportional (T == S..) and the too-short error (T < S)."""
+    rng = np.random.default_rng(6)
+    lps, toks = [], []
+    for (T, S) in [(20, 6), (20, 7), (20, 9), (20, 10), (20, 19), (20, 20), (12, 12), (9, 10), (5, 9), (1, 1), (2, 1)]:
+        lp, tk, _ = cases.planted_case(rng, T, S, C=67, peak=5.0)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, 67, 66)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0)
+    _compare(res, exp, T_len)
+    assert (res.status.cpu().numpy() == 1).sum() == 2
+
+
+def test_simple_mode_parity(ora, gpu_device):
+    rng = np.random.default_rng(7)
+    lp, tk, T_len, S_len = _mk_batch(rng, 48, 67, (40, 400), (1, 60), peak=4.0)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0, simple=True, boost=False, enf=False)
+    _compare(res, exp, T_len)
+
+
+def test_long_paths_R_classes(ora, gpu_device):
+    """CTC paths of 65..1000 states exercise every states-per-lane class of K1."""
+    rng = np.random.default_rng(8)
+    lps, toks = [], []
+    for S in (17, 33, 50, 64, 70, 100, 130, 200, 249):
+        T = 4 * S + int(rng.integers(1, 60))
+        lp, tk, _ = cases.planted_case(rng, T, S, C=67, peak=7.0)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, 67, 66)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0)
+    _compare(res, exp, T_len)
+
+
+def test_confidences_parity(ora, gpu_device):
+    from bournemouth_forced_aligner_amd import calculate_confidences_batch
+    rng = np.random.default_rng(9)
+    lp, tk, T_len, S_len = _mk_batch(rng, 24, 67, (40, 300), (1, 40), peak=3.0)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0)
+    # widen the tuples so that ranges overlap neighbours (exercises the aliasing replay)
+    segs = res.segs.cpu().numpy().copy()
+    cnt = res.seg_count.cpu().numpy()
+    for b in range(segs.shape[0]):
+        for i in range(cnt[b]):
+            segs[b, i, 1] = max(0, segs[b, i, 1] - int(rng.integers(0, 4)))
+            segs[b, i, 2] = segs[b, i, 2] + int(rng.integers(0, 6))
+    lpd = torch.from_numpy(lp).to(gpu_device)
+    conf, status = calculate_confidences_batch(lpd, torch.from_numpy(segs), torch.from_numpy(cnt))
+    conf = conf.cpu().numpy()
+    for b in range(segs.shape[0]):
+        rc, c, s, e = ora.confidences(lp[b], [tuple(r) for r in segs[b, :cnt[b]]])
+        assert rc == 0
+        np.testing.assert_allclose(conf[b, :cnt[b]], c, atol=1e-4, rtol=0)
+        assert (conf[b, :cnt[b]].view(np.int32) == c.view(np.int32)).all()
