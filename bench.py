@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned frames/s of the MI355X forced-alignment core on synthetic ph66 posteriors.
+
+A "step" is one pass of the hot path (bfa_align_batch: planning + K1 banded Viterbi forward with
+fused boost/log_softmax/floor + K2 backtrace + K3 run-length encoding) over one batch of
+device-resident log-probabilities.  Workload at every N: BASELINE.json configs[2]
+("batch=4096 T=1000 |tokens|=40 ph66") PER GPU (weak scaling; utterances are independent, so ranks
+share nothing and the data path has no collective).
+
+One JSON line is printed by rank 0.  `roofline` prices the dominant kernel (K1) with the
+algorithmic bytes of SURVEY.md section 8(d): 4*C + ceil(L/4) + 8 bytes per frame.
+`cpu_baseline` times the C restatement of the reference (oracle/, kind "port") on the host.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synth_batch(B, T, S, C, seed, device, peak=9.0):
+    """Planted-path posteriors: tokens iid uniform on 1..C-2 (no SIL, no blank),
+    random monotone segmentation with >= 2 frames per token, logits = N(0,1) + peak*onehot(planted),
+    log_probs = log_softmax(logits).  Generated on the device with a seeded torch generator."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    blank = C - 1
+    toks = torch.randint(1, C - 1, (B, S), generator=g, device=device)
+    extra = T - 2 * S
+    assert extra >= 0
+    cuts, _ = torch.sort(torch.randint(0, extra + 1, (B, 2 * S), generator=g, device=device), dim=1)
+    zeros = torch.zeros((B, 1), dtype=cuts.dtype, device=device)
+    full = torch.full((B, 1), extra, dtype=cuts.dtype, device=device)
+    sizes = torch.diff(torch.cat([zeros, cuts, full], dim=1), dim=1)  # [B, 2S+1] gap,tok,gap,tok,...,gap
+    sizes[:, 1::2] += 2
+    ends = torch.cumsum(sizes, dim=1)  # slot k covers [ends[k-1], ends[k])
+    t = torch.arange(T, device=device).unsqueeze(0).expand(B, T).contiguous()
+    slot = torch.searchsorted(ends, t, right=True)  # [B,T] in 0..2S
+    is_tok = (slot % 2) == 1
+    tok_idx = torch.clamp((slot - 1) // 2, 0, S - 1)
+    planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
+    logits = torch.randn((B, T, C), generator=g, device=device, dtype=torch.float32)
+    logits.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, T, 1), peak, device=device))
+    lp = torch.log_softmax(logits, dim=-1)
+    return lp, toks.to(torch.int32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--tokens", type=int, default=40)
+    ap.add_argument("--classes", type=int, default=67)
+    ap.add_argument("--cpu-sample", type=int, default=1536, help="utterances timed on the host oracle (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch, _lib
+
+    B, T, S, C = args.batch, args.frames, args.tokens, args.classes
+    blank, sil = C - 1, 0
+    # two distinct batches so consecutive steps never stream the same 1.1 GB (> the 256 MB Infinity Cache anyway)
+    bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev) for i in range(2)]
+    T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
+    S_len = torch.full((B,), S, dtype=torch.int32, device=dev)
+    au = AlignmentUtils(blank_id=blank, silence_id=sil)  # reference defaults: anchors 10, boost, floor, truly_forced
+    lib = _lib.lib()
+    h = _lib.handle(local_rank)
+
+    def step(i):
+        lp, tk = bufs[i % 2]
+        return au.decode_alignments_device(lp, tk, T_len, S_len)
+
+    for i in range(args.warmup):
+        res = step(i)
+    torch.cuda.synchronize()
+    st = res.status.cpu().numpy()
+    assert (st == 0).all(), f"alignment failed on the bench workload: {np.unique(st)}"
+
+    lib.bfa_profile_enable(h, 1)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.bfa_profile_enable(h, 0)
+    k1 = (ctypes.c_float * max(1, args.steps))()
+    nk1 = lib.bfa_profile_collect(h, k1, args.steps)
+    k1_ms = float(np.mean([k1[i] for i in range(nk1)])) if nk1 > 0 else float("nan")
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # confidence pass (utils._calculate_confidences), timed separately: it is a separate reference call
+    lp0, _ = bufs[0]
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(5):
+        conf, _st = calculate_confidences_batch(lp0, res.segs, res.seg_count)
+    torch.cuda.synchronize()
+    conf_ms = (time.perf_counter() - c0) / 5 * 1e3
+
+    # final gather of the (small) result records over RCCL, outside the timed steps
+    gather_ms = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        out = [torch.empty_like(res.segs) for _ in range(world)] if rank == 0 else None
+        dist.gather(res.segs, out, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    frames_per_step = B * T
+    L = 4 * S + 1
+    bytes_per_frame = 4 * C + (L + 3) // 4 + 8
+    value = world * frames_per_step * args.steps / elapsed
+    achieved = frames_per_step * bytes_per_frame / (k1_ms * 1e-3) / 1e9 if k1_ms == k1_ms else None
+
+    cpu = None
+    if rank == 0 and not args.no_cpu and args.cpu_sample > 0:
+        from oracle import oracle as ora
+        n = min(args.cpu_sample, B)
+        lp_h = bufs[0][0][:n].cpu().numpy()
+        tk_h = bufs[0][1][:n].cpu().numpy()
+        prm = ora.make_params(blank, sil)
+        ora.decode_alignments(lp_h[:4], tk_h[:4], [T] * 4, [S] * 4, prm, seg_cap=S + 2)  # warm
+        w0 = time.perf_counter()
+        exp = ora.decode_alignments(lp_h, tk_h, [T] * n, [S] * n, prm, seg_cap=S + 2)
+        w = time.perf_counter() - w0
+        cpu = {"value": n * T / w, "unit": "aligned frames/s", "cores": 1, "kind": "port",
+               "sample": f"{n} utterances of T={T} S={S} C={C} (same synthetic batch), oracle/bfa_oracle.c single thread, {w:.1f} s"}
+        # the bench doubles as a full-size parity check on that sample
+        got = res if (args.steps % 2 == 1) else step(0)
+        torch.cuda.synchronize()
+        gs = got.segs[:n].cpu().numpy()
+        gc = got.seg_count[:n].cpu().numpy()
+        mism = int((gc != exp["seg_count"]).sum())
+        for b in range(n):
+            if gc[b] == exp["seg_count"][b] and not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all():
+                mism += 1
+        cpu["parity_mismatching_utterances"] = mism
+
+    if rank == 0:
+        line = {
+            "metric": "aligned frames/sec (whole node) on ph66 posteriors", "value": value,
+            "unit": "aligned frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch={B} T={T} |tokens|={S} ph66 (C={C}) per GPU, reference-default flags "
+                                   f"(boost+floor+truly_forced, anchors=10, no SIL in targets -> standard mode)",
+                       "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": "k_dp (K1 banded Viterbi forward)", "kernel_ms": k1_ms,
+                         "algorithmic_bytes_per_frame": bytes_per_frame},
+            "cpu_baseline": cpu,
+            "confidence_pass_ms": conf_ms,
+            "gather_ms": gather_ms,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

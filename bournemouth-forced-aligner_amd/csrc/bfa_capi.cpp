@@ -8,10 +8,12 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "bfa_types.hpp"
 
-extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream);
+extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                                       int C, void *stream);
@@ -23,6 +25,9 @@ struct bfa_context {
     int device;
     int num_cu;
     std::string err;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // recorded K1 brackets
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // reusable pairs
 };
 
 namespace {
@@ -139,8 +144,34 @@ int bfa_create(bfa_handle *out, int device)
     return BFA_OK;
 }
 
+int bfa_profile_enable(bfa_handle h, int on)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    h->profile = on != 0;
+    return BFA_OK;
+}
+
+int bfa_profile_collect(bfa_handle h, float *out_ms_host, int cap)
+{
+    if (!h || (!out_ms_host && cap > 0)) return BFA_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    for (auto &pr : h->events) {
+        float ms = 0.0f;
+        (void)hipEventSynchronize(pr.second);
+        (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+        if (n < cap) out_ms_host[n++] = ms;
+        h->pool.push_back(pr);
+    }
+    h->events.clear();
+    return n;
+}
+
 int bfa_destroy(bfa_handle h)
 {
+    if (h) {
+        for (auto &pr : h->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto &pr : h->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    }
     delete h;
     return BFA_OK;
 }
@@ -197,7 +228,15 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
     int grid = l.item_cap < 65536 ? l.item_cap : 65536;
-    const int rc = bfa_launch_align(&a, grid, stream);
+    void *ev0 = nullptr, *ev1 = nullptr;
+    if (h->profile) {
+        std::pair<hipEvent_t, hipEvent_t> pr;
+        if (!h->pool.empty()) { pr = h->pool.back(); h->pool.pop_back(); }
+        else { (void)hipEventCreate(&pr.first); (void)hipEventCreate(&pr.second); }
+        h->events.push_back(pr);
+        ev0 = (void *)pr.first; ev1 = (void *)pr.second;
+    }
+    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }

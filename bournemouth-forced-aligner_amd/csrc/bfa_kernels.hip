@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
                         const uint32_t wd = sbp[(((t >> 2) - q0) * W + (sr >> 2)) * 64 + sl];
                         const int k = (int)((wd >> (8 * (t & 3) + 2 * (sr & 3))) & 3u);
                         s -= k; sr -= k;
-                        if (sr < 0) { sr += R; sl -= 1; }
+                        while (sr < 0) { sr += R; sl -= 1; } // k = 2 crosses two lanes when R == 1
                         if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap
                     }
                 }
@@ -682,13 +682,14 @@ __global__ __launch_bounds__(256) void k_log_softmax(const float *in, int64_t ld
 // -------------------------------------------------------------------------------------------------
 // launchers used by bfa_capi.cpp
 // -------------------------------------------------------------------------------------------------
-extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_)
+extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
     const AlignArgs &a = *args;
     const int nk = (a.C + 15) / 16;
     hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
+    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
     // classes of CTC path length that can occur: L <= 4*Smax+1 (and L <= 1.2*Tmax in segmented mode)
     const int rmax = r_class_for_L(4 * a.Smax + 1) ? r_class_for_L(4 * a.Smax + 1) : MAX_R;
 #define BFA_LAUNCH_DP(R_)                                                                                          \
@@ -700,6 +701,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     BFA_LAUNCH_DP(1) BFA_LAUNCH_DP(2) BFA_LAUNCH_DP(3) BFA_LAUNCH_DP(4)
     BFA_LAUNCH_DP(6) BFA_LAUNCH_DP(8) BFA_LAUNCH_DP(12) BFA_LAUNCH_DP(16)
 #undef BFA_LAUNCH_DP
+    if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
     hipLaunchKernelGGL(k_backtrace, dim3(dp_grid), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     return (int)hipGetLastError();

