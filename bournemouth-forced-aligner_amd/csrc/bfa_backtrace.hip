@@ -1,0 +1,126 @@
+// bfa_backtrace.hip -- K2: backtrace over the packed backpointers + framewise outputs
+// (forced_alignment.py:686-700), plus the non-DP fills (proportional :170-172, silence :382-397).
+//
+// One wavefront per work item.  The serial dependence state[t-1] = bp[t][state[t]] is only a real
+// dependence at frames where the path moves (k != 0): about L of the T frames.  So instead of one
+// step per frame, all 64 lanes look at 64 consecutive frames at once for the CURRENT state, a ballot
+// finds the latest frame with a move, every frame above it takes the current state, the state is
+// updated and the search continues below that frame: ~ (#moves + T/64) wave steps per utterance.
+#include <hip/hip_runtime.h>
+
+#include "bfa_math.hpp"
+#include "bfa_types.hpp"
+
+namespace bfa {
+
+constexpr int BT_CH = 64; // frames per LDS chunk (16 quads)
+
+__global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
+{
+    __shared__ uint32_t sbp[16 * 4 * 64]; // 16 quads x (W <= 4) x (nl <= 64)
+    const int lane = threadIdx.x & 63;
+    const DevParams &p = a.p;
+    const int n_items = a.counters[0];
+    for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
+        const Item it = a.items[i];
+        const int b = it.utt;
+        int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
+        int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
+        const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
+        if (it.kind == ITEM_FILL_BLANK) {
+            for (int t = lane; t < it.nout; t += 64) { oph[it.out0 + t] = p.blank; oid[it.out0 + t] = -1; }
+            continue;
+        }
+        if (it.kind == ITEM_FILL_PROP) { // forced_alignment.py:170-172
+            for (int t = lane; t < it.nout; t += 64) {
+                const int fi = (int)(((int64_t)t * it.nt) / it.nout);
+                oph[it.out0 + t] = tok[fi]; oid[it.out0 + t] = it.tok0 + fi;
+            }
+            continue;
+        }
+        if (it.kind == ITEM_FILL_SIL) { // forced_alignment.py:382-397
+            const double fps = (it.nt > 0) ? (double)it.nout / (double)it.nt : 0.0;
+            for (int t = lane; t < it.nout; t += 64) {
+                int id = -1;
+                if (it.nt > 0) { // the k with int(k*fps) <= t < int((k+1)*fps); the ranges are disjoint
+                    const int k = (int)((double)t / fps);
+                    for (int kk = max(0, k - 1); kk <= min(it.nt - 1, k + 1); ++kk) {
+                        const int f0 = (int)((double)kk * fps), f1 = (int)((double)(kk + 1) * fps);
+                        if (t >= f0 && t < f1) id = it.tok0 + kk;
+                    }
+                }
+                oph[it.out0 + t] = p.sil; oid[it.out0 + t] = id;
+            }
+            continue;
+        }
+        if (it.kind != ITEM_DP) continue;
+
+        const int R = r_class_for_L(it.L);
+        const int W = bp_words_for_R(R);
+        const int Ts = it.Ts, L = it.L;
+        const int nl = bp_lanes(L, R);
+        const uint32_t *bp = a.bp + it.bp_off;
+        int s = it.final_state;          // wave-uniform walk state
+        int sl = s / R, sr = s - sl * R; // its (lane, register slot)
+        const int nchunks = (Ts + BT_CH - 1) / BT_CH;
+        for (int c = nchunks - 1; c >= 0; --c) {
+            const int t0 = c * BT_CH;
+            const int t1 = min(Ts, t0 + BT_CH);
+            const int q0 = t0 >> 2, q1 = (t1 + 3) >> 2;
+            const int ndw = (q1 - q0) * W * nl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int d = lane; d < ndw; d += 64) sbp[d] = bp[(int64_t)q0 * W * nl + d];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            const int t = t0 + lane;    // this lane's frame
+            const int qrow = ((t >> 2) - q0) * W;
+            const int fsh = 8 * (t & 3);
+            const bool mine = t < t1;
+            int my_state = 0;
+            int t_hi = t1 - 1;          // frames (.., t_hi] still to be labelled in this chunk
+            while (t_hi >= t0) {
+                // backpointer code of this lane's frame for the CURRENT state (state[t-1] = s - k at frame t)
+                uint32_t k = 0;
+                if (mine && t <= t_hi && t > 0) {
+                    const uint32_t wd = sbp[(qrow + (sr >> 2)) * nl + sl];
+                    k = (wd >> (fsh + 2 * (sr & 3))) & 3u;
+                }
+                const unsigned long long mv = __ballot(k != 0);
+                if (mv == 0) { // the path stays in s down to the chunk start
+                    if (mine && t <= t_hi) my_state = s;
+                    t_hi = t0 - 1;
+                    break;
+                }
+                const int jl = 63 - __builtin_clzll(mv); // latest frame (lane) at which the path moves
+                if (mine && t <= t_hi && lane >= jl) my_state = s;
+                const int kk = (int)__builtin_amdgcn_readlane((int)k, jl);
+                s -= kk; sr -= kk;
+                while (sr < 0) { sr += R; sl -= 1; }
+                if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap (:692)
+                t_hi = t0 + jl - 1;
+            }
+            if (mine) {
+                const int o = t - it.pad_left; // :447-448 trim the boundary padding
+                if (o >= 0 && o < it.nout) {
+                    int ph = p.blank, id = -1;
+                    if (my_state >= 1) {
+                        const int q = (my_state - 1) / it.stride;
+                        if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
+                    }
+                    oph[it.out0 + o] = ph;
+                    oid[it.out0 + o] = id;
+                }
+            }
+        }
+    }
+}
+
+} // namespace bfa
+
+extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bfa::k_backtrace, dim3(grid), dim3(64), 0, stream, *args);
+}

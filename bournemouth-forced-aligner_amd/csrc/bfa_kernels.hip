@@ -12,8 +12,7 @@
 // No MFMA anywhere: this is a memory-streaming scan with ~13 float ops per CTC state per frame.
 #include <hip/hip_runtime.h>
 
-#include "bfa_math.hpp"
-#include "bfa_types.hpp"
+#include "bfa_softmax.hpp"
 
 #pragma clang fp contract(off)
 
@@ -114,374 +113,6 @@ __global__ void k_plan(AlignArgs a)
     a.status[b] = status;
     a.umode[b] = mode;
     a.seg_count[b] = 0;
-}
-
-// =================================================================================================
-// softmax of four posterior rows at once: lane = 16*g + j handles row g, columns j, 16+j, 32+j, ...
-// =================================================================================================
-struct RowLane {
-    uint32_t valid; // bit k : column 16k+j exists
-    uint32_t tmask; // bit k : column 16k+j is a boosted / floored target
-    int blank_k;    // k such that column 16k+j is the blank column, or -1
-};
-
-template <int NK>
-__device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid)
-{
-    float mx = x[0];
-#pragma unroll
-    for (int k = 1; k < NK; ++k)
-        if (valid & (1u << k)) mx = __builtin_fmaxf(mx, x[k]);
-    mx = row16_max(mx);
-    float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        x[k] = x[k] - mx;
-        const float e = expf_u10(x[k]);
-        if (k == 0) acc = e;
-        else if (valid & (1u << k)) acc = acc + e;
-    }
-    const float ls = logf_u10(row16_butterfly_add(acc));
-#pragma unroll
-    for (int k = 0; k < NK; ++k) x[k] = x[k] - ls;
-}
-
-// forced_alignment.py:29-83 (+ :543-561 when anchor_cnt > 0) applied to the register-resident quad
-template <int NK>
-__device__ __forceinline__ void prepare_quad(float (&x)[NK], const RowLane &rl, bool boost, bool enforce,
-                                             bool anchored, int anchor_cnt)
-{
-    if (boost) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-            if (rl.tmask & (1u << k)) x[k] = x[k] + 5.0f;
-        softmax16<NK>(x, rl.valid);
-    }
-    if (enforce) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-            if ((rl.tmask & (1u << k)) && x[k] < MIN_LOGP) x[k] = MIN_LOGP;
-    }
-    if (anchored) {
-        // silence anchoring of this row (segmented mode only): counts differ between the four rows of
-        // the quad, so run the maximum count on the whole wave and keep only the wanted iterations
-        int maxcnt = anchor_cnt;
-        maxcnt = max(maxcnt, __shfl_xor(maxcnt, 16));
-        maxcnt = max(maxcnt, __shfl_xor(maxcnt, 32));
-        for (int i = 0; i < maxcnt; ++i) {
-            float y[NK];
-#pragma unroll
-            for (int k = 0; k < NK; ++k) y[k] = (k == rl.blank_k) ? x[k] + 5.0f : x[k];
-            softmax16<NK>(y, rl.valid);
-            if (i < anchor_cnt) {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) x[k] = y[k];
-            }
-        }
-    }
-}
-
-// =================================================================================================
-// K1 : banded CTC Viterbi forward, one DP per wavefront
-// =================================================================================================
-__device__ __forceinline__ int path_col(int s, int stride, int nt, const int32_t *tok, int blank)
-{
-    if (s < 1) return blank;
-    const int q = (s - 1) / stride;
-    if ((s - 1) - q * stride != 0 || q >= nt) return blank;
-    return tok[q];
-}
-
-template <int R, int NK>
-__device__ __forceinline__ int dp_item(const AlignArgs &a, const Item &it, float *sm)
-{
-    constexpr int LDW = 16 * NK;   // floats per staged row
-    constexpr int W = (R + 3) / 4; // backpointer dwords per lane per 4 frames
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, j = lane & 15;
-    const DevParams &p = a.p;
-    const int b = it.utt;
-    const int Ts = it.Ts, L = it.L, nt = it.nt, stride = it.stride;
-    const float *lp = a.logp + (int64_t)b * a.strideB + (int64_t)it.row0 * a.strideT;
-    const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
-    const bool anchored = it.anchored != 0;
-    const uint8_t *anch = a.anchor + (int64_t)b * a.Tmax + it.row0;
-    const bool boost = p.boost && !p.simple, enforce = p.enforce && !p.simple;
-
-    // ---- per-lane constants of the softmax role
-    RowLane rl;
-    rl.valid = 0; rl.tmask = 0; rl.blank_k = -1;
-    {
-        const uint32_t *um = a.umask + (int64_t)b * MASK_WORDS;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int c = 16 * k + j;
-            if (c < a.C) {
-                rl.valid |= 1u << k;
-                if ((um[c >> 5] >> (c & 31)) & 1u) rl.tmask |= 1u << k;
-                if (c == p.blank) rl.blank_k = k;
-            }
-        }
-    }
-    // ---- per-lane constants of the DP role: states s = lane*R + r
-    int col[R];
-    uint32_t skipm = 0; // bit r : can_skip[s]  (forced_alignment.py:603-605)
-    float fs[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int s = lane * R + r;
-        col[r] = (s < L) ? path_col(s, stride, nt, tok, p.blank) : p.blank;
-        const int c2 = path_col(s - 2, stride, nt, tok, p.blank);
-        if (s >= 2 && s < L && col[r] != c2) skipm |= 1u << r;
-        fs[r] = (float)s;
-    }
-    float dp[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) dp[r] = NEG; // :582
-
-    const bool use_band = (it.bw > 0 && Ts > 1 && L > 1); // :586
-    const double pace = use_band ? (double)(L - 1) / (double)(Ts - 1) : 0.0;
-    const float pace32 = use_band ? (float)(L - 1) / (float)(Ts - 1) : 0.0f;
-    const double bwd = (double)it.bw;
-    const float bwf = (float)it.bw;
-
-    uint32_t *bp = a.bp + it.bp_off;
-    const int nq = (Ts + 3) >> 2;
-
-    float x[NK], xn[NK];
-    auto load_quad = [&](float(&dst)[NK], int q) {
-        int row = 4 * q + g;
-        if (row > Ts - 1) row = Ts - 1;
-        const float *rp = lp + (int64_t)row * a.strideT;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int c = 16 * k + j;
-            dst[k] = (c < a.C) ? rp[c] : 0.0f;
-        }
-    };
-    load_quad(x, 0);
-#pragma unroll
-    for (int k = 0; k < NK; ++k) xn[k] = x[k];
-
-    for (int q = 0; q < nq; ++q) {
-        if (q + 1 < nq) load_quad(xn, q + 1); // prefetch while this quad is normalised and consumed
-        int acnt = 0;
-        if (anchored) {
-            int row = 4 * q + g;
-            if (row > Ts - 1) row = Ts - 1;
-            acnt = anch[row];
-        }
-        prepare_quad<NK>(x, rl, boost, enforce, anchored, acnt);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) sm[g * LDW + 16 * k + j] = x[k];
-        wave_lds_sync();
-
-        uint32_t word[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) word[w] = 0u;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const int t = 4 * q + f;
-            if (t < Ts) {
-                float e[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) e[r] = sm[f * LDW + col[r]];
-                if (t == 0) { // :594-596
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int s = lane * R + r;
-                        if (s == 0) dp[r] = e[r];
-                        if (s == 1 && L > 1) dp[r] = e[r];
-                    }
-                } else {
-                    // values of the two states left of this lane's first state
-                    const float l1 = dpp_mov<DPP_WAVE_SHR1>(NEG, dp[R - 1]);
-                    float l2;
-                    if constexpr (R >= 2) l2 = dpp_mov<DPP_WAVE_SHR1>(NEG, dp[R >= 2 ? R - 2 : 0]);
-                    else l2 = dpp_mov<DPP_WAVE_SHR1>(NEG, l1);
-                    float lo = 0.0f, hi = 0.0f;
-                    if (use_band) { // :650-653
-                        if (p.simple) { const float c = (float)t * pace32; lo = c - bwf; hi = c + bwf; }
-                        else { const double c = (double)t * pace; lo = (float)(c - bwd); hi = (float)(c + bwd); }
-                    }
-                    float nd[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float p1 = (r >= 1) ? dp[(r >= 1) ? r - 1 : 0] : l1;
-                        const float p2 = (r >= 2) ? dp[(r >= 2) ? r - 2 : 0] : ((r == 1) ? l1 : l2);
-                        const float c0 = dp[r] + e[r];
-                        float c1 = p1 + e[r];
-                        float c2 = p2 + e[r];
-                        if (r == 0 && lane == 0) c1 = NEG;  // s == 0 has no advance  (:616-617)
-                        if (!(skipm & (1u << r))) c2 = NEG; // (:620-625, :642)
-                        const float best = __builtin_fmaxf(__builtin_fmaxf(c0, c1), c2);
-                        const uint32_t k = (c0 == best) ? 0u : ((c1 == best) ? 1u : 2u); // first maximum (:645)
-                        word[r >> 2] |= k << (8 * f + 2 * (r & 3));
-                        float v = best;
-                        if (use_band && (fs[r] < lo || fs[r] > hi)) v = NEG;
-                        nd[r] = v;
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) dp[r] = nd[r];
-                }
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < W; ++w) bp[((int64_t)q * W + w) * 64 + lane] = word[w];
-        wave_lds_sync(); // every lane is done reading sm before the next quad overwrites it
-#pragma unroll
-        for (int k = 0; k < NK; ++k) x[k] = xn[k];
-    }
-
-    // ---- final state (forced_alignment.py:656-682)
-    int f;
-    {
-        int rm = -1;                  // rightmost state with dp > NEG
-        float bv = 0.0f; int bi = -1; // best among dp > NEG (first maximum)
-        float av = 0.0f; int ai = -1; // best among all (first maximum)
-        float vL1 = NEG, vL2 = NEG;   // dp[L-1], dp[L-2]  (only "<= NEG" is tested, see below)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int s = lane * R + r;
-            if (s < L) {
-                if (dp[r] > NEG) { rm = s; if (bi < 0 || dp[r] > bv) { bv = dp[r]; bi = s; } }
-                if (ai < 0 || dp[r] > av) { av = dp[r]; ai = s; }
-                if (s == L - 1) vL1 = dp[r];
-                if (s == L - 2) vL2 = dp[r];
-            }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            rm = max(rm, __shfl_xor(rm, off));
-            // a value below NEG is replaced by NEG here; both are "<= NEG", the only test made
-            vL1 = __builtin_fmaxf(vL1, __shfl_xor(vL1, off));
-            vL2 = __builtin_fmaxf(vL2, __shfl_xor(vL2, off));
-            const float obv = __shfl_xor(bv, off); const int obi = __shfl_xor(bi, off);
-            if (obi >= 0 && (bi < 0 || obv > bv || (obv == bv && obi < bi))) { bv = obv; bi = obi; }
-            const float oav = __shfl_xor(av, off); const int oai = __shfl_xor(ai, off);
-            if (oai >= 0 && (ai < 0 || oav > av || (oav == av && oai < ai))) { av = oav; ai = oai; }
-        }
-        if (!p.truly_forced) {
-            f = (bi >= 0) ? bi : ai;
-        } else {
-            f = L - 1;
-            float v = vL1;
-            if (v <= NEG && L >= 2) { f = L - 2; v = vL2; }
-            if (v <= NEG) f = (rm >= 0) ? rm : (L - 1);
-        }
-    }
-    return f;
-}
-
-// One kernel per (R, NK): the register budget of a wave is set by its own R, so short CTC paths keep
-// the occupancy that hides HBM latency.  Every launch walks the whole item list and takes the items
-// of its class; the host launches only the classes the shapes allow.
-template <int R, int NK>
-__global__ __launch_bounds__(64) void k_dp(AlignArgs a)
-{
-    __shared__ float sm[4 * 16 * NK];
-    const int n_items = a.counters[0];
-    for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
-        const Item it = a.items[i];
-        if (it.kind != ITEM_DP || r_class_for_L(it.L) != R) continue;
-        const int f = dp_item<R, NK>(a, it, sm);
-        if ((threadIdx.x & 63) == 0) a.items[i].final_state = f;
-    }
-}
-
-// =================================================================================================
-// K2 : backtrace + frame outputs.  One wavefront per item.
-// =================================================================================================
-__global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
-{
-    constexpr int CH = 64; // frames per LDS chunk (16 quads)
-    __shared__ uint32_t sbp[16 * 4 * 64]; // up to W=4 dwords per lane per quad
-    __shared__ int sst[CH];
-    const int lane = threadIdx.x & 63;
-    const DevParams &p = a.p;
-    const int n_items = a.counters[0];
-    for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
-        const Item it = a.items[i];
-        const int b = it.utt;
-        int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
-        int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
-        const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
-        if (it.kind == ITEM_FILL_BLANK) {
-            for (int t = lane; t < it.nout; t += 64) { oph[it.out0 + t] = p.blank; oid[it.out0 + t] = -1; }
-            continue;
-        }
-        if (it.kind == ITEM_FILL_PROP) { // forced_alignment.py:170-172
-            for (int t = lane; t < it.nout; t += 64) {
-                const int fi = (int)(((int64_t)t * it.nt) / it.nout);
-                oph[it.out0 + t] = tok[fi]; oid[it.out0 + t] = it.tok0 + fi;
-            }
-            continue;
-        }
-        if (it.kind == ITEM_FILL_SIL) { // forced_alignment.py:382-397
-            const double fps = (it.nt > 0) ? (double)it.nout / (double)it.nt : 0.0;
-            for (int t = lane; t < it.nout; t += 64) {
-                int id = -1;
-                if (it.nt > 0) { // the k with int(k*fps) <= t < int((k+1)*fps); the ranges are disjoint
-                    const int k = (int)((double)t / fps);
-                    for (int kk = max(0, k - 1); kk <= min(it.nt - 1, k + 1); ++kk) {
-                        const int f0 = (int)((double)kk * fps), f1 = (int)((double)(kk + 1) * fps);
-                        if (t >= f0 && t < f1) id = it.tok0 + kk;
-                    }
-                }
-                oph[it.out0 + t] = p.sil; oid[it.out0 + t] = id;
-            }
-            continue;
-        }
-        if (it.kind != ITEM_DP) continue;
-
-        const int R = r_class_for_L(it.L);
-        const int W = bp_words_for_R(R);
-        const int Ts = it.Ts, L = it.L;
-        const uint32_t *bp = a.bp + it.bp_off;
-        int s = it.final_state;
-        int sl = s / R, sr = s - sl * R; // (lane, slot) of the current state
-        const int nchunks = (Ts + CH - 1) / CH;
-        for (int c = nchunks - 1; c >= 0; --c) {
-            const int t0 = c * CH;
-            const int t1 = min(Ts, t0 + CH);
-            const int q0 = t0 >> 2, q1 = (t1 + 3) >> 2;
-            const int ndw = (q1 - q0) * W * 64;
-            wave_lds_sync();
-            for (int d = lane; d < ndw; d += 64) sbp[d] = bp[(int64_t)q0 * W * 64 + d];
-            wave_lds_sync();
-            if (lane == 0) {
-                for (int t = t1 - 1; t >= t0; --t) {
-                    sst[t - t0] = s;
-                    if (t > 0) { // state[t-1] = bp[t][state[t]]  (:691-692)
-                        const uint32_t wd = sbp[(((t >> 2) - q0) * W + (sr >> 2)) * 64 + sl];
-                        const int k = (int)((wd >> (8 * (t & 3) + 2 * (sr & 3))) & 3u);
-                        s -= k; sr -= k;
-                        while (sr < 0) { sr += R; sl -= 1; } // k = 2 crosses two lanes when R == 1
-                        if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap
-                    }
-                }
-            }
-            wave_lds_sync();
-            // s/sl/sr were advanced by lane 0 only: broadcast for the next chunk
-            s = __builtin_amdgcn_readfirstlane(s);
-            sl = __builtin_amdgcn_readfirstlane(sl);
-            sr = __builtin_amdgcn_readfirstlane(sr);
-            const int t = t0 + lane;
-            if (t < t1) {
-                const int o = t - it.pad_left; // :447-448 trim the boundary padding
-                if (o >= 0 && o < it.nout) {
-                    const int st = sst[lane];
-                    int ph = p.blank, id = -1;
-                    if (st >= 1) {
-                        const int q = (st - 1) / it.stride;
-                        if ((st - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
-                    }
-                    oph[it.out0 + o] = ph;
-                    oid[it.out0 + o] = id;
-                }
-            }
-        }
-    }
 }
 
 // =================================================================================================
@@ -682,6 +313,11 @@ __global__ __launch_bounds__(256) void k_log_softmax(const float *in, int64_t ld
 // -------------------------------------------------------------------------------------------------
 // launchers used by bfa_capi.cpp
 // -------------------------------------------------------------------------------------------------
+extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, int rmax, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, int rmax, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, int rmax, int grid, hipStream_t stream);
+extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream);
+
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1)
 {
     using namespace bfa;
@@ -690,19 +326,14 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const int nk = (a.C + 15) / 16;
     hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
-    // classes of CTC path length that can occur: L <= 4*Smax+1 (and L <= 1.2*Tmax in segmented mode)
-    const int rmax = r_class_for_L(4 * a.Smax + 1) ? r_class_for_L(4 * a.Smax + 1) : MAX_R;
-#define BFA_LAUNCH_DP(R_)                                                                                          \
-    if ((R_) <= rmax) {                                                                                           \
-        if (nk <= 2) hipLaunchKernelGGL((k_dp<R_, 2>), dim3(dp_grid), dim3(64), 0, stream, a);                    \
-        else if (nk <= 5) hipLaunchKernelGGL((k_dp<R_, 5>), dim3(dp_grid), dim3(64), 0, stream, a);               \
-        else hipLaunchKernelGGL((k_dp<R_, 8>), dim3(dp_grid), dim3(64), 0, stream, a);                            \
-    }
-    BFA_LAUNCH_DP(1) BFA_LAUNCH_DP(2) BFA_LAUNCH_DP(3) BFA_LAUNCH_DP(4)
-    BFA_LAUNCH_DP(6) BFA_LAUNCH_DP(8) BFA_LAUNCH_DP(12) BFA_LAUNCH_DP(16)
-#undef BFA_LAUNCH_DP
+    // register tiers of K1 that can occur: L <= 4*Smax+1
+    const int rc = r_class_for_L(4 * a.Smax + 1);
+    const int rmax = rc ? rc : MAX_R;
+    if (nk <= 2) bfa_launch_dp_nk2(&a, rmax, dp_grid, stream);
+    else if (nk <= 5) bfa_launch_dp_nk5(&a, rmax, dp_grid, stream);
+    else bfa_launch_dp_nk8(&a, rmax, dp_grid, stream);
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
-    hipLaunchKernelGGL(k_backtrace, dim3(dp_grid), dim3(64), 0, stream, a);
+    bfa_launch_backtrace(&a, dp_grid, stream);
     hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,89 @@
+// bfa_softmax.hpp -- four posterior rows per wavefront: lane = 16*g + j handles row g and the
+// columns j, 16+j, 32+j, ...  This is exactly the lane/accumulator structure of the reference's
+// host log_softmax (see bfa_math.hpp), so the result is bit-identical to it.
+#pragma once
+#include "bfa_math.hpp"
+#include "bfa_types.hpp"
+
+#pragma clang fp contract(off)
+
+namespace bfa {
+
+struct RowLane {
+    uint32_t valid; // bit k : column 16k+j exists
+    uint32_t tmask; // bit k : column 16k+j is a boosted / floored target
+    int blank_k;    // k such that column 16k+j is the blank column, or -1
+};
+
+__device__ __forceinline__ RowLane make_rowlane(int nk, int j, int C, int blank, const uint32_t *um)
+{
+    RowLane rl;
+    rl.valid = 0; rl.tmask = 0; rl.blank_k = -1;
+    for (int k = 0; k < nk; ++k) {
+        const int c = 16 * k + j;
+        if (c < C) {
+            rl.valid |= 1u << k;
+            if (um && ((um[c >> 5] >> (c & 31)) & 1u)) rl.tmask |= 1u << k;
+            if (c == blank) rl.blank_k = k;
+        }
+    }
+    return rl;
+}
+
+template <int NK>
+__device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid)
+{
+    float mx = x[0];
+#pragma unroll
+    for (int k = 1; k < NK; ++k)
+        if (valid & (1u << k)) mx = __builtin_fmaxf(mx, x[k]);
+    mx = row16_max(mx);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        x[k] = x[k] - mx;
+        const float e = expf_u10(x[k]);
+        if (k == 0) acc = e;
+        else acc = (valid & (1u << k)) ? (acc + e) : acc;
+    }
+    const float ls = logf_u10(row16_butterfly_add(acc));
+#pragma unroll
+    for (int k = 0; k < NK; ++k) x[k] = x[k] - ls;
+}
+
+// silence anchoring (forced_alignment.py:543-561): `cnt` times { x[blank] += 5 ; x = log_softmax(x) }.
+// The four rows of a quad may carry different counts: iterate to the wave maximum and mask.
+template <int NK>
+__device__ __forceinline__ void anchor_rows(float (&x)[NK], const RowLane &rl, int cnt)
+{
+    int maxcnt = cnt;
+    maxcnt = max(maxcnt, __shfl_xor(maxcnt, 16));
+    maxcnt = max(maxcnt, __shfl_xor(maxcnt, 32));
+    for (int i = 0; i < maxcnt; ++i) {
+        float y[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) y[k] = (k == rl.blank_k) ? x[k] + 5.0f : x[k];
+        softmax16<NK>(y, rl.valid);
+        if (i < cnt) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) x[k] = y[k];
+        }
+    }
+}
+
+// forced_alignment.py:29-83: +5 on target columns, log_softmax, floor target columns at log(1e-8)
+template <int NK>
+__device__ __forceinline__ void boost_floor(float (&x)[NK], const RowLane &rl, bool boost, bool enforce)
+{
+    if (boost) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) x[k] = (rl.tmask & (1u << k)) ? (x[k] + 5.0f) : x[k];
+        softmax16<NK>(x, rl.valid);
+    }
+    if (enforce) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) x[k] = ((rl.tmask & (1u << k)) && x[k] < MIN_LOGP) ? MIN_LOGP : x[k];
+    }
+}
+
+} // namespace bfa

@@ -96,12 +96,15 @@ __host__ __device__ inline int r_class_for_L(int L)
 }
 __host__ __device__ inline int bp_words_for_R(int R) { return (R + 3) / 4; } // dwords per lane per 4 frames
 
-// dwords of backpointer storage for one DP of Ts rows and path length L
+// Backpointer block of one DP: [quad][w][lane] dwords, lane < nl = ceil(L/R) (only lanes that own a
+// state are stored).  Dword w of lane l holds, for the four frames of the quad, the 2-bit codes of the
+// lane's register slots 4w..4w+3:  bits [8*f + 2*(r&3), +2) = k(frame 4q+f, state l*R + r).
+__host__ __device__ inline int bp_lanes(int L, int R) { return (L + R - 1) / R; }
 __host__ __device__ inline int64_t bp_dwords(int Ts, int L)
 {
     const int R = r_class_for_L(L);
     const int64_t quads = (Ts + 3) / 4;
-    if (R > 0) return quads * bp_words_for_R(R) * 64;
+    if (R > 0) return quads * bp_words_for_R(R) * bp_lanes(L, R);
     return (int64_t)Ts * ((L + 15) / 16); // big-L kernel: 2 bits per state, row-major
 }
 
