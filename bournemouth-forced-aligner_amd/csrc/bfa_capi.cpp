@@ -225,6 +225,7 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     a.p.ignore_noise = params->ignore_noise; a.p.truly_forced = params->truly_forced;
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = params->simple;
     a.p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
+    a.p.class_mask = (uint32_t)params->reserved[0];
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
     int grid = l.item_cap < 65536 ? l.item_cap : 65536;

@@ -313,9 +313,9 @@ __global__ __launch_bounds__(256) void k_log_softmax(const float *in, int64_t ld
 // -------------------------------------------------------------------------------------------------
 // launchers used by bfa_capi.cpp
 // -------------------------------------------------------------------------------------------------
-extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, int rmax, int grid, hipStream_t stream);
-extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, int rmax, int grid, hipStream_t stream);
-extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, int rmax, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
 extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1)
@@ -323,15 +323,18 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
     const AlignArgs &a = *args;
+    const DevParams &p = a.p;
     const int nk = (a.C + 15) / 16;
     hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
-    // register tiers of K1 that can occur: L <= 4*Smax+1
-    const int rc = r_class_for_L(4 * a.Smax + 1);
-    const int rmax = rc ? rc : MAX_R;
-    if (nk <= 2) bfa_launch_dp_nk2(&a, rmax, dp_grid, stream);
-    else if (nk <= 5) bfa_launch_dp_nk5(&a, rmax, dp_grid, stream);
-    else bfa_launch_dp_nk8(&a, rmax, dp_grid, stream);
+    // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
+    unsigned mask = r_class_mask_upto(4 * a.Smax + 1);
+    if (p.class_mask) mask &= p.class_mask;
+    const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0;
+    const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
+    if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, stream);
+    else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, stream);
+    else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, stream);
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
     bfa_launch_backtrace(&a, dp_grid, stream);
     hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);

@@ -42,6 +42,7 @@ struct Item {
 
 struct DevParams {
     int32_t blank, sil, anchors, ignore_noise, truly_forced, boost, enforce, simple, max_blanks;
+    uint32_t class_mask; // K1 classes to launch (host hint), 0 = derive from the shapes
 };
 
 // everything the kernels of one bfa_align_batch call need; passed by value
@@ -81,10 +82,10 @@ struct ConfArgs {
     int32_t *status;
 };
 
+// states-per-lane class of a CTC path of L states (0 = too long for the wave kernel)
 __host__ __device__ inline int r_class_for_L(int L)
 {
     const int r = (L + 63) / 64;
-    if (r <= 1) return 1;
     if (r <= 2) return 2;
     if (r <= 3) return 3;
     if (r <= 4) return 4;
@@ -92,7 +93,22 @@ __host__ __device__ inline int r_class_for_L(int L)
     if (r <= 8) return 8;
     if (r <= 12) return 12;
     if (r <= 16) return 16;
-    return 0; // too long for the wave kernel
+    return 0;
+}
+__host__ __device__ inline unsigned r_class_bit(int R)
+{
+    switch (R) {
+    case 2: return 1u; case 3: return 2u; case 4: return 4u; case 6: return 8u;
+    case 8: return 16u; case 12: return 32u; case 16: return 64u; default: return 0u;
+    }
+}
+// all classes up to and including the class of L
+__host__ __device__ inline unsigned r_class_mask_upto(int L)
+{
+    const int R = r_class_for_L(L);
+    if (R == 0) return 127u;
+    const unsigned bit = r_class_bit(R);
+    return bit | (bit - 1u);
 }
 __host__ __device__ inline int bp_words_for_R(int R) { return (R + 3) / 4; } // dwords per lane per 4 frames
 

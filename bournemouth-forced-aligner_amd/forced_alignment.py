@@ -123,8 +123,47 @@ class ViterbiDecoder:
         p.max_blanks = int(max_blanks)
         return p
 
+    @staticmethod
+    def _r_class(L):
+        r = (L + 63) // 64
+        for i, c in enumerate((2, 3, 4, 6, 8, 12, 16)):
+            if r <= c:
+                return i
+        return None
+
+    def class_mask_hint(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False):
+        """Optional host-side hint for bfa_params.reserved[0]: the K1 states-per-lane classes that occur
+        in this batch, from HOST copies of the lengths.  `has_sil` says whether any target may contain the
+        silence id (then the segmented mode can create shorter DPs, and every class up to the largest is
+        kept).  Without a hint the library launches every class the tensor shapes allow."""
+        mask, top = 0, -1
+        for T, S in zip(T_lens, S_lens):
+            T, S = int(T), int(S)
+            if S <= 0:
+                continue
+            if simple:
+                f32 = np.float32
+                stride = 4
+                if f32(stride * S + 1) > f32(T) * f32(0.9):
+                    stride = 3
+                if f32(stride * S + 1) > f32(T) * f32(0.8):
+                    stride = 2
+            else:
+                stride = 4
+                for s2 in (3, 2, 1):
+                    if stride * S + 1 > T:
+                        stride = s2
+            c = self._r_class(stride * S + 1)
+            if c is None:
+                continue
+            mask |= 1 << c
+            top = max(top, self._r_class(4 * S + 1) or 6)
+        if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and top >= 0:
+            mask |= (1 << (top + 1)) - 1
+        return mask
+
     def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
-                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10):
+                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
         """Whole-batch device call (bfa_align_batch).  Returns an AlignmentResult of device tensors; nothing
         is synchronised or copied to the host here."""
         if log_probs.dim() != 3:
@@ -143,6 +182,7 @@ class ViterbiDecoder:
         S_len = _as_i32(true_seqs_lens, dev)
         T_len = _as_i32(pred_lens, dev)
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
+        params.reserved[0] = int(class_mask)
         if seg_cap is None:
             seg_cap = Smax + 2 if self.ignore_noise else Tmax + 1
         L = _lib.lib()
@@ -232,11 +272,12 @@ class AlignmentUtils:
                                               ignore_noise=ignore_noise, truly_forced=self.truly_forced)
 
     def decode_alignments_device(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True,
-                                 enforce_minimum=True, seg_cap=None):
+                                 enforce_minimum=True, seg_cap=None, class_mask=0):
         """decode_alignments without the host round trip: returns an AlignmentResult (device tensors)."""
         return self.viterbi_decoder.align_batch(log_probs, true_seqs, pred_lens, true_seqs_lens,
                                                 boost_targets=boost_targets, enforce_minimum=enforce_minimum,
-                                                anchor_pauses=self.silence_anchors > 0, seg_cap=seg_cap)
+                                                anchor_pauses=self.silence_anchors > 0, seg_cap=seg_cap,
+                                                class_mask=class_mask)
 
     def decode_alignments(self, log_probs, true_seqs=None, pred_lens=None, true_seqs_lens=None,
                           forced_alignment=True, boost_targets=True, enforce_minimum=True, debug=False):

@@ -75,7 +75,8 @@ typedef struct {
     int32_t enforce_minimum; /* default 1 : floor target columns at log(1e-8) */
     int32_t simple;          /* 1 = decode_alignments_simple semantics (forced_alignment.py:932-987) */
     int32_t max_blanks;      /* assort_frames(max_blanks=10) */
-    int32_t reserved[3];
+    int32_t reserved[3];     /* [0] : optional host hint, bit mask of K1 states-per-lane classes
+                                {2,3,4,6,8,12,16} worth launching (0 = derive from the shapes) */
 } bfa_params;
 
 /* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),
