@@ -13,11 +13,16 @@
 
 namespace bfa {
 
-constexpr int BT_CH = 64; // frames per LDS chunk (16 quads)
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
 {
-    __shared__ uint32_t sbp[16 * 4 * 64]; // 16 quads x (W <= 4) x (nl <= 64)
+    __shared__ uint32_t sbp[16 * 64]; // one chunk: (16/W) quads x W x (nl <= 64) dwords
     const int lane = threadIdx.x & 63;
     const DevParams &p = a.p;
     const int n_items = a.counters[0];
@@ -62,18 +67,32 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
         const uint32_t *bp = a.bp + it.bp_off;
         int s = it.final_state;          // wave-uniform walk state
         int sl = s / R, sr = s - sl * R; // its (lane, register slot)
-        const int nchunks = (Ts + BT_CH - 1) / BT_CH;
-        for (int c = nchunks - 1; c >= 0; --c) {
-            const int t0 = c * BT_CH;
-            const int t1 = min(Ts, t0 + BT_CH);
-            const int q0 = t0 >> 2, q1 = (t1 + 3) >> 2;
+        // chunk = CQ quads (4*CQ frames, <= 64) = CQ*W*nl <= 1024 dwords, i.e. <= 16 dwords per lane
+        const int CQ = 16 / W;
+        const int CF = 4 * CQ;
+        const int nchunks = (Ts + CF - 1) / CF;
+        uint32_t pre[16]; // next chunk, in flight in registers while the current one is walked
+        auto fetch = [&](int c) {
+            const int q0 = c * CQ;
+            const int q1 = min((Ts + 3) >> 2, q0 + CQ);
             const int ndw = (q1 - q0) * W * nl;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int d = lane; d < ndw; d += 64) sbp[d] = bp[(int64_t)q0 * W * nl + d];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t *src = bp + (int64_t)q0 * W * nl;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const int idx = d * 64 + lane;
+                pre[d] = (idx < ndw) ? src[idx] : 0u;
+            }
+        };
+        fetch(nchunks - 1);
+        for (int c = nchunks - 1; c >= 0; --c) {
+            const int t0 = c * CF;
+            const int t1 = min(Ts, t0 + CF);
+            const int q0 = t0 >> 2;
+            wave_sync_lds();
+#pragma unroll
+            for (int d = 0; d < 16; ++d) sbp[d * 64 + lane] = pre[d];
+            wave_sync_lds();
+            if (c > 0) fetch(c - 1);
 
             const int t = t0 + lane;    // this lane's frame
             const int qrow = ((t >> 2) - q0) * W;

@@ -228,7 +228,8 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     a.p.class_mask = (uint32_t)params->reserved[0];
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
-    int grid = l.item_cap < 65536 ? l.item_cap : 65536;
+    // one wavefront per work item; surplus items are taken by the blocks' stride loops
+    int grid = l.item_cap < 16384 ? l.item_cap : 16384;
     void *ev0 = nullptr, *ev1 = nullptr;
     if (h->profile) {
         std::pair<hipEvent_t, hipEvent_t> pr;

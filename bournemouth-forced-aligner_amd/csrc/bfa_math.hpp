@@ -93,6 +93,12 @@ __device__ __forceinline__ float dpp_mov(float old, float v)
     return as_f(__builtin_amdgcn_update_dpp(as_i(old), as_i(v), CTRL, 0xf, 0xf, false));
 }
 constexpr int DPP_WAVE_SHR1 = 0x138; // lane l <- lane l-1 across the whole wave64, lane 0 keeps `old`
+// lane l <- lane l-1; lane 0 receives 0 (bound_ctrl), which lets the compiler fold the move into the
+// consuming VALU instruction as a DPP operand
+__device__ __forceinline__ float wave_shr1_zero(float v)
+{
+    return as_f(__builtin_amdgcn_update_dpp(0, as_i(v), DPP_WAVE_SHR1, 0xf, 0xf, true));
+}
 constexpr int DPP_ROW_ROR8 = 0x128;  // rotate within each 16-lane row
 constexpr int DPP_ROW_ROR4 = 0x124;
 constexpr int DPP_ROW_ROR2 = 0x122;
