@@ -60,7 +60,7 @@ Layout layout_for(int B, int Tmax, int Smax, const bfa_params *p)
     Layout l;
     const bool seg = segmented_possible(p);
     const int Lmax = 4 * (Smax > 0 ? Smax : 1) + 1;
-    const int nseg_max = seg ? (Smax + 3) : 0; // speech + silence pieces of one utterance
+    const int nseg_max = seg ? (Smax + 4) : 0; // speech + silence pieces of one utterance + blank tail
     l.item_cap = B + (seg ? B * nseg_max : 0);
     const int R = bfa::r_class_for_L(Lmax);
     const int64_t quads = (Tmax + 3) / 4 + (seg ? 3 * (int64_t)(Smax / 2 + 2) : 0);
@@ -79,8 +79,12 @@ size_t carve_all(Carve &c, int B, int Tmax, int Smax, const bfa_params *p, const
     auto uT = c.take<int32_t>((size_t)B);
     auto uS = c.take<int32_t>((size_t)B);
     auto umode = c.take<int32_t>((size_t)B);
-    auto anchor = c.take<uint8_t>(seg ? (size_t)B * Tmax : 1);
+    const int anchor_per_utt = Tmax + 6 * (Smax / 2 + 2);
+    const int scratch_per_utt = 2 * (Smax + 2) + 4 * (Tmax + 2) + 2 * (Smax + 2) + 5 * (2 * Smax + 6);
+    auto anchor = c.take<uint8_t>(seg ? (size_t)B * anchor_per_utt : 1);
     auto psil = c.take<float>(seg ? (size_t)B * Tmax : 1);
+    auto cand = c.take<int32_t>((size_t)B);
+    auto seg_scratch = c.take<int32_t>(seg ? (size_t)B * scratch_per_utt : 1);
     int32_t *fph = nullptr, *fidx = nullptr;
     if (need_frames) {
         fph = c.take<int32_t>((size_t)B * Tmax);
@@ -89,7 +93,8 @@ size_t carve_all(Carve &c, int B, int Tmax, int Smax, const bfa_params *p, const
     auto bp = c.take<uint32_t>((size_t)B * (size_t)l.bp_per_utt);
     if (a) {
         a->items = items; a->item_cap = l.item_cap; a->counters = counters; a->umask = umask; a->uT = uT; a->uS = uS;
-        a->umode = umode; a->anchor = anchor; a->psil = psil; a->bp = bp; a->bp_cap = (int64_t)B * l.bp_per_utt;
+        a->umode = umode; a->anchor = anchor; a->anchor_per_utt = anchor_per_utt; a->psil = psil; a->cand = cand;
+        a->seg_scratch = seg_scratch; a->seg_scratch_per_utt = scratch_per_utt; a->bp = bp; a->bp_cap = (int64_t)B * l.bp_per_utt;
         a->bp_per_utt = l.bp_per_utt;
         if (need_frames) { a->frame_ph = fph; a->frame_idx = fidx; }
     }

@@ -35,7 +35,9 @@ __device__ __forceinline__ int band_standard(int L) { return (L > 60) ? ((L / 4 
 __global__ void k_plan(AlignArgs a)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) a.counters[0] = a.B; // one item slot per utterance; the segmented planner appends more
+    // counters[] are zeroed by a memset node ahead of this kernel; one item slot per utterance, the
+    // segmented planner appends more
+    if (b == 0) a.counters[0] = a.B;
     if (b >= a.B) return;
     const DevParams &p = a.p;
     const int Traw = a.T_len ? a.T_len[b] : a.Tmax;
@@ -66,7 +68,7 @@ __global__ void k_plan(AlignArgs a)
 
     Item it;
     it.kind = ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = T; it.tok0 = 0; it.nt = S; it.stride = 0; it.L = 0;
-    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = 0; it.anchored = 0;
+    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = 0; it.anch_off = -1;
     it.bp_off = (int64_t)b * a.bp_per_utt;
     int mode = BFA_MODE_EMPTY;
 
@@ -103,7 +105,10 @@ __global__ void k_plan(AlignArgs a)
             it.bw = band_standard(L);
             mode = BFA_MODE_STANDARD;
         }
-        if (seg_candidate) mode = -1 - mode; // k_plan_segmented decides (it may keep this fallback)
+        if (seg_candidate && status == BFA_ITEM_OK) { // k_plan_segmented decides (it may keep this fallback)
+            mode = -1 - mode;
+            a.cand[atomicAdd(&a.counters[1], 1)] = b;
+        }
     }
     if (it.kind == ITEM_DP && r_class_for_L(it.L) == 0) {
         status = BFA_ITEM_TOO_LARGE; // TODO(big-L workgroup kernel)
@@ -317,6 +322,7 @@ extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, unsigned class_mas
 extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
 extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream);
+extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1)
 {
@@ -325,7 +331,9 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const AlignArgs &a = *args;
     const DevParams &p = a.p;
     const int nk = (a.C + 15) / 16;
+    (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
     hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
+    if (!p.simple && p.anchors > 0 && p.sil >= 0) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
     unsigned mask = r_class_mask_upto(4 * a.Smax + 1);

@@ -36,7 +36,7 @@ struct Item {
     int32_t nout;      // output frames
     int32_t pad_left;  // out0 - row0
     int32_t final_state;
-    int32_t anchored;  // 1 = some rows of this DP carry silence-anchor counts
+    int32_t anch_off;  // >= 0: offset of this DP's per-row silence-anchor counts in the utterance's pool; -1: none
     int64_t bp_off;    // dword offset of this item's backpointer block in the workspace
 };
 
@@ -59,12 +59,16 @@ struct AlignArgs {
     // workspace carve
     Item *items;
     int32_t item_cap;
-    int32_t *counters;      // [0] = number of items, [1] = bp dwords used (lo), [2] spare
+    int32_t *counters;      // [0] = number of items, [1] = number of segmented-mode candidates
     uint32_t *umask;        // [B][MASK_WORDS] target-column bit mask
     int32_t *uT, *uS;       // [B] clamped lengths
     int32_t *umode;         // [B] decode mode (negative while the segmented planner is undecided)
-    uint8_t *anchor;        // [B][Tmax] silence-anchor counts (segmented mode)
-    float *psil;            // [B][Tmax] exp(m[:,SIL]) (segmented mode)
+    uint8_t *anchor;        // [B][anchor_per_utt] per-DP silence-anchor counts (segmented mode)
+    int32_t anchor_per_utt;
+    float *psil;            // [B][Tmax] exp(m[:,SIL]) of the boosted/floored rows (segmented mode)
+    int32_t *cand;          // [B] utterances whose target contains SIL (candidates for the segmented mode)
+    int32_t *seg_scratch;   // [B][seg_scratch_per_utt] planner scratch
+    int32_t seg_scratch_per_utt;
     uint32_t *bp;           // backpointer pool
     int64_t bp_cap;         // dwords
     int64_t bp_per_utt;     // dwords reserved for the one-DP-per-utterance case

@@ -143,3 +143,41 @@ def test_confidences_parity(ora, gpu_device):
         assert rc == 0
         np.testing.assert_allclose(conf[b, :cnt[b]], c, atol=1e-4, rtol=0)
         assert (conf[b, :cnt[b]].view(np.int32) == c.view(np.int32)).all()
+
+
+@pytest.mark.parametrize("anchors", [10, 3, 5])
+def test_segmented_mode_parity(ora, gpu_device, anchors):
+    """Targets with SIL and planted silences: silence detection, matching, per-segment DPs with
+    boundary padding and silence anchoring, silence fills -- and the fall-backs to standard mode."""
+    rng = np.random.default_rng(300 + anchors)
+    lps, toks = [], []
+    for i in range(64):
+        T = int(rng.integers(60, 500))
+        S = int(rng.integers(3, max(4, T // 6)))
+        lp, tk, _ = cases.planted_case(rng, T, S, C=67, peak=float(rng.choice([9.0, 5.0, 3.0])),
+                                       sil_rate=float(rng.choice([0.1, 0.2, 0.35])), sil_len=(4, 40), repeat_rate=0.05)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, 67, 66)
+    for tf in (True, False):
+        res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=anchors, tf=tf)
+        _compare(res, exp, T_len)
+    md = res.mode.cpu().numpy()
+    assert (md == 1).sum() >= 5, "test inputs did not exercise the segmented mode"
+    assert (md == 2).sum() >= 1
+
+
+def test_segmented_mode_group_head_and_flags(ora, gpu_device):
+    rng = np.random.default_rng(41)
+    lps, toks = [], []
+    for i in range(40):
+        T = int(rng.integers(80, 400))
+        S = int(rng.integers(3, T // 6))
+        lp, tk, _ = cases.planted_case(rng, T, S, C=17, peak=6.0, sil_rate=0.25, sil_len=(8, 30))
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, 17, 16)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 17, anchors=10)
+    _compare(res, exp, T_len)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 17, anchors=10, boost=False, enf=True, ign=False)
+    _compare(res, exp, T_len)
