@@ -6,8 +6,10 @@ There is no CPU implementation in this package: without the HIP library or witho
 alignment entry points raise.
 """
 from .forced_alignment import AlignmentUtils, ViterbiDecoder  # noqa: F401
-from .utils import _calculate_confidences, convert_to_ms, calculate_confidences_batch, log_softmax  # noqa: F401
+from .utils import (_calculate_confidences, convert_to_ms, calculate_confidences_batch, log_softmax,  # noqa: F401
+                    postprocess_batch)
+from .core import PhonemeTimestampAligner  # noqa: F401
 
 __all__ = ["AlignmentUtils", "ViterbiDecoder", "_calculate_confidences", "convert_to_ms",
-           "calculate_confidences_batch", "log_softmax"]
+           "calculate_confidences_batch", "log_softmax", "postprocess_batch", "PhonemeTimestampAligner"]
 __version__ = "0.1.0"

@@ -1,0 +1,214 @@
+"""API surface of bournemouth_aligner/core.py::PhonemeTimestampAligner for the accelerated path.
+
+Only the part of the reference class that sits on the hot path is mirrored: decoder setup
+(core.py:252-257), extract_timestamps_from_segment_batch (core.py:811-992) from the log-softmax
+onwards, and the thin process_sentence / process_sentences_batch / process_segments wrappers
+(core.py:1553-1616, 1212).  The acoustic model (CUPE-2i) and the espeak phonemiser are NOT part of
+this package: they are injected as callables and stay on PyTorch-ROCm / the host.
+
+    posterior_fn(wavs, wav_lens) -> (logits_class [B,T,C_p], logits_group [B,T,C_g], spectral_lens list[int])
+    phonemizer(text)             -> dict(ph66=[ids], pg16=[group ids] (optional), words/word_num/eipa (optional))
+"""
+import numpy as np
+import torch
+
+from .forced_alignment import AlignmentUtils
+from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
+
+
+class PhonemeTimestampAligner:
+    def __init__(self, posterior_fn=None, phonemizer=None, phoneme_id_to_group_id=None, blank_class=66,
+                 silence_class=0, blank_group=16, silence_group=0, device="cuda", silence_anchors=10,
+                 boost_targets=True, enforce_minimum=True, enforce_all_targets=True, ensure_completeness=False,
+                 ignore_noise=True, extend_soft_boundaries=True, boundary_softness=3, sample_rate=16000,
+                 phoneme_id_to_label=None, group_id_to_label=None):
+        if ensure_completeness:
+            raise NotImplementedError("ensure_completeness=True (core.py:516-657) is outside the accelerated path")
+        self.posterior_fn = posterior_fn
+        self.phonemizer = phonemizer
+        self.phoneme_id_to_group_id = phoneme_id_to_group_id
+        self.blank_class, self.silence_class = blank_class, silence_class
+        self.blank_group, self.silence_group = blank_group, silence_group
+        self.device = torch.device(device)
+        self.silence_anchors = silence_anchors
+        self.boost_targets = boost_targets
+        self.enforce_minimum = enforce_minimum
+        self.enforce_all_targets = enforce_all_targets
+        self.ensure_completeness = ensure_completeness
+        self.ignore_noise = ignore_noise
+        self.extend_soft_boundaries = extend_soft_boundaries
+        self.boundary_softness = boundary_softness
+        self.resampler_sample_rate = sample_rate
+        self.phoneme_id_to_label = phoneme_id_to_label or {}
+        self.group_id_to_label = group_id_to_label or {}
+        self._setup_decoders()
+
+    def _setup_decoders(self):
+        """core.py:252-257"""
+        self.alignment_utils_g = AlignmentUtils(blank_id=self.blank_group, silence_id=self.silence_group,
+                                                silence_anchors=self.silence_anchors, ignore_noise=self.ignore_noise,
+                                                truly_forced=self.enforce_all_targets)
+        self.alignment_utils_p = AlignmentUtils(blank_id=self.blank_class, silence_id=self.silence_class,
+                                                silence_anchors=self.silence_anchors, ignore_noise=self.ignore_noise,
+                                                truly_forced=self.enforce_all_targets)
+
+    def _map_phonemes_to_groups(self, seq):
+        if self.phoneme_id_to_group_id is None:
+            raise ValueError("group_sequences not given and no phoneme_id_to_group_id mapping was configured")
+        return [self.phoneme_id_to_group_id.get(int(p), self.blank_group) for p in seq]
+
+    # ---- one head: align -> coverage -> soft boundaries -> confidences, all on the device
+    def _head(self, utils, log_probs, seqs, seq_lens, spectral_lens):
+        res = utils.decode_alignments_device(log_probs, seqs, spectral_lens, seq_lens,
+                                             boost_targets=self.boost_targets, enforce_minimum=self.enforce_minimum)
+        postprocess_batch(log_probs, seq_lens, res.segs, res.seg_count, extend=self.extend_soft_boundaries,
+                          boundary_softness=self.boundary_softness)
+        conf, cstat = calculate_confidences_batch(log_probs, res.segs, res.seg_count)  # padded rows (core.py:936)
+        return res, conf, cstat
+
+    def extract_timestamps_from_logits(self, logits_class, logits_group, spectral_lens, phoneme_sequences, wav_lens,
+                                       start_offset_times=0, group_sequences=None, do_groups=True):
+        """core.py:897-964 given the model's logits.  Returns list[B] of dicts with 'phoneme_timestamps' and
+        'group_timestamps': lists of (id, start_frame, end_frame, target_seq_idx, is_estimated, confidence,
+        start_ms, end_ms)."""
+        dev = self.device
+        B = logits_class.shape[0]
+        if isinstance(phoneme_sequences, torch.Tensor):
+            ph_seq_lens = [int((row != self.blank_class).sum()) for row in phoneme_sequences]  # core.py:844
+            ph = phoneme_sequences.to(torch.int32)
+        else:
+            ph_seq_lens = [len(s) for s in phoneme_sequences]
+            smax = max(1, max(ph_seq_lens))
+            ph = torch.full((B, smax), self.blank_class, dtype=torch.int32)
+            for b, s in enumerate(phoneme_sequences):
+                ph[b, :len(s)] = torch.as_tensor(list(s), dtype=torch.int32)
+        if group_sequences is None:
+            rows = [self._map_phonemes_to_groups(ph[b, :ph_seq_lens[b]].tolist()) for b in range(B)]
+            group_sequences = rows
+        if not isinstance(group_sequences, torch.Tensor):
+            gmax = max(1, max(len(s) for s in group_sequences))
+            gr = torch.full((B, gmax), self.blank_group, dtype=torch.int32)
+            for b, s in enumerate(group_sequences):
+                gr[b, :len(s)] = torch.as_tensor(list(s), dtype=torch.int32)
+        else:
+            gr = group_sequences.to(torch.int32)
+        spec = [int(x) for x in spectral_lens]
+        lp_p = log_softmax(logits_class.to(dev))  # core.py:898-899
+        lp_g = log_softmax(logits_group.to(dev))
+        heads = [("phoneme_timestamps", self.alignment_utils_p, lp_p, ph)]
+        heads.append(("group_timestamps", self.alignment_utils_g, lp_g, gr))  # always runs (core.py:914)
+        out = [dict() for _ in range(B)]
+        pending = []
+        for key, utils, lp, seqs in heads:
+            pending.append((key, self._head(utils, lp, seqs, ph_seq_lens, spec)))
+        for key, (res, conf, cstat) in pending:
+            res.raise_for_status()
+            if int((cstat.cpu() != 0).sum()) != 0:
+                raise IndexError("confidence pass: phoneme id or start frame out of range")
+            cnt = res.seg_count.cpu().numpy()
+            segs = res.segs.cpu().numpy()
+            cf = conf.cpu().numpy()
+            for b in range(B):
+                rows = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), False, float(cf[b, i]))
+                        for i, r in enumerate(segs[b, :cnt[b]])]
+                off = start_offset_times[b] if isinstance(start_offset_times, (list, tuple)) else start_offset_times
+                rows = convert_to_ms(rows, torch.tensor(spec[b]), off, wav_lens[b], self.resampler_sample_rate)
+                out[b][key] = sorted(rows, key=lambda x: x[6])  # core.py:955-956
+        return out
+
+    def extract_timestamps_from_segment_batch(self, wavs, wav_lens, phoneme_sequences, start_offset_times=0,
+                                              group_sequences=None, extract_embeddings=False, do_groups=True,
+                                              debug=False):
+        """core.py:811-992 (embeddings pooling is not part of the accelerated path)."""
+        if self.posterior_fn is None:
+            raise AssertionError("CUPE extractor model is not loaded: pass posterior_fn=...")  # core.py:886
+        if extract_embeddings:
+            raise NotImplementedError("extract_embeddings=True is outside the accelerated path")
+        logits_class, logits_group, spectral_lens = self.posterior_fn(wavs, wav_lens)
+        ts = self.extract_timestamps_from_logits(logits_class, logits_group, spectral_lens, phoneme_sequences,
+                                                 wav_lens, start_offset_times, group_sequences, do_groups)
+        n = len(ts)
+        return ts, [None] * n, [None] * n
+
+    # ---- thin wrappers (core.py:1212, 1553, 1586)
+    def _post_process_segment(self, segment, ts, phoneme_timestamps, group_timestamps=None):
+        """core.py:1140-1210 (fields of 'phoneme_ts' / 'group_ts'; word alignment and coverage analysis are host
+        text utilities outside this package)."""
+        out = dict(segment)
+        out["ipa"] = ts.get("eipa", "")
+        out["phoneme_ts"] = [
+            {"phoneme_id": int(p), "phoneme_label": self.phoneme_id_to_label.get(p, f"UNK_{p}"),
+             "ipa_label": out["ipa"][tidx] if 0 <= tidx < len(out["ipa"]) else "overflow",
+             "start_ms": float(sms), "end_ms": float(ems), "confidence": float(c), "is_estimated": bool(est),
+             "target_seq_idx": int(tidx), "index": i}
+            for i, (p, sf, ef, tidx, est, c, sms, ems) in enumerate(phoneme_timestamps)]
+        if group_timestamps is not None:
+            out["group_ts"] = [
+                {"group_id": int(g), "group_label": self.group_id_to_label.get(g, f"UNK_{g}"), "start_ms": float(sms),
+                 "end_ms": float(ems), "confidence": float(c), "is_estimated": bool(est), "target_seq_idx": int(tidx),
+                 "index": i}
+                for i, (g, sf, ef, tidx, est, c, sms, ems) in enumerate(group_timestamps)]
+        return out
+
+    def process_segments(self, srt_data, audio_wavs, extract_embeddings=False, do_groups=False, batch_size=16,
+                         debug=False):
+        """core.py:1212-1470: srt_data = {'segments': [{'start','end','text'}, ...]} (or a list of those, one per
+        clip).  Needs the injected phonemizer and posterior_fn."""
+        if self.phonemizer is None:
+            raise ValueError("process_segments needs a phonemizer(text) callable (espeak is not part of this package)")
+        single = isinstance(srt_data, dict)
+        clips = [srt_data] if single else list(srt_data)
+        wavs = [audio_wavs] if single or isinstance(audio_wavs, torch.Tensor) and audio_wavs.dim() == 1 else list(audio_wavs)
+        results = []
+        for clip, wav in zip(clips, wavs):
+            wav = wav.reshape(-1) if isinstance(wav, torch.Tensor) else torch.as_tensor(wav).reshape(-1)
+            segs_out = []
+            segs = clip["segments"]
+            for i0 in range(0, len(segs), batch_size):
+                chunk = segs[i0:i0 + batch_size]
+                tss = [self.phonemizer(s["text"]) for s in chunk]
+                pieces, lens = [], []
+                for s in chunk:
+                    a = int(s["start"] * self.resampler_sample_rate)
+                    e = int(s["end"] * self.resampler_sample_rate)
+                    pieces.append(wav[a:e])
+                    lens.append(int(pieces[-1].numel()))
+                wmax = max(lens)
+                batch = torch.zeros((len(chunk), wmax), dtype=torch.float32)
+                for b, pc in enumerate(pieces):
+                    batch[b, :lens[b]] = pc
+                seqs = [list(t["ph66"]) for t in tss]
+                groups = [list(t["pg16"]) for t in tss] if all("pg16" in t for t in tss) else None
+                try:
+                    ts_dicts, _, _ = self.extract_timestamps_from_segment_batch(
+                        batch, lens, seqs, start_offset_times=[s["start"] for s in chunk], group_sequences=groups,
+                        extract_embeddings=False, do_groups=do_groups, debug=debug)
+                except ValueError:
+                    ts_dicts = [None] * len(chunk)  # core.py:1367-1386: the chunk yields empty results
+                for s, t, d in zip(chunk, tss, ts_dicts):
+                    if d is None:
+                        segs_out.append(dict(s, phoneme_ts=[], group_ts=[]))
+                    else:
+                        segs_out.append(self._post_process_segment(s, t, d["phoneme_timestamps"],
+                                                                   d["group_timestamps"] if do_groups else None))
+            results.append({"segments": segs_out})
+        return results[0] if single else results
+
+    def process_sentence(self, text, audio_wav, extract_embeddings=False, do_groups=False, debug=False):
+        """core.py:1553-1584: one sentence, one clip."""
+        wav = audio_wav if isinstance(audio_wav, torch.Tensor) else torch.as_tensor(np.asarray(audio_wav))
+        dur = wav.reshape(-1).numel() / self.resampler_sample_rate
+        srt = {"segments": [{"start": 0.0, "end": dur, "text": text}]}
+        return self.process_segments(srt, wav, extract_embeddings=extract_embeddings, do_groups=do_groups, debug=debug)
+
+    def process_sentences_batch(self, texts, audio_wavs, extract_embeddings=False, do_groups=False, batch_size=16,
+                                debug=False):
+        """core.py:1586-1616: one sentence per clip."""
+        srts = []
+        for text, w in zip(texts, audio_wavs):
+            n = (w if isinstance(w, torch.Tensor) else torch.as_tensor(np.asarray(w))).reshape(-1).numel()
+            srts.append({"segments": [{"start": 0.0, "end": n / self.resampler_sample_rate, "text": text}]})
+        return self.process_segments(srts, list(audio_wavs), extract_embeddings=extract_embeddings, do_groups=do_groups,
+                                     batch_size=batch_size, debug=debug)
+
+    process_batch = process_sentences_batch  # the name BASELINE.json uses

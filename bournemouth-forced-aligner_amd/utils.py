@@ -79,7 +79,8 @@ def convert_to_ms(framestamps, spectral_length, start_offset_time, wav_len, samp
     duration_in_seconds = float(wav_len) / float(sample_rate)
     f32 = np.float32
     if tensor_mode:
-        dpf = f32(duration_in_seconds) / f32(sl) if sl > 0 else f32(0)
+        # python float / int64 tensor dispatches to Tensor.__rtruediv__ = tensor.reciprocal() * other
+        dpf = (f32(1) / f32(sl)) * f32(duration_in_seconds) if sl > 0 else f32(0)
     else:
         dpf = duration_in_seconds / sl if sl > 0 else 0
     out = []
@@ -117,3 +118,25 @@ def log_softmax(logits):
                                torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, h, "bfa_log_softmax")
     return out
+
+
+def postprocess_batch(log_probs, S_len, segs, seg_count, extend=True, boundary_softness=3):
+    """core.py:925-931 on the device, in place on `segs` / `seg_count`: ensure_target_coverage with
+    ensure_completeness=False (drops target_idx -1 / >= S, stable sort by start) and, if `extend`,
+    extend_soft_boundaries_func over the padded rows (bfa_postprocess)."""
+    dev = _device_of(log_probs)
+    lp = log_probs.to(device=dev, dtype=torch.float32)
+    if lp.stride(2) != 1:
+        lp = lp.contiguous()
+    B, Tmax, C = lp.shape
+    assert segs.is_cuda and segs.dtype == torch.int32 and segs.is_contiguous()
+    assert seg_count.is_cuda and seg_count.dtype == torch.int32
+    S_len = _as_i32(S_len, dev)
+    L = _lib.lib()
+    h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+    with torch.cuda.device(dev):
+        rc = L.bfa_postprocess(h, lp.data_ptr(), lp.stride(0), lp.stride(1), B, Tmax, C, S_len.data_ptr(),
+                               segs.data_ptr(), segs.shape[1], seg_count.data_ptr(), int(bool(extend)),
+                               int(boundary_softness), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, h, "bfa_postprocess")
+    return segs, seg_count

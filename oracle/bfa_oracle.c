@@ -777,7 +777,8 @@ void ora_convert_to_ms(const int32_t *seg4, int n, int spectral_len, double star
                        double sample_rate, float *start_ms, float *end_ms)
 {
     double dur = wav_len / sample_rate;                                            /* :126 python float */
-    float dpf = spectral_len > 0 ? (float)dur / (float)spectral_len : 0.0f;        /* :127 float32 tensor */
+    /* :127 python float / 0-dim int64 tensor -> Tensor.__rtruediv__ = tensor.reciprocal() * other (float32) */
+    float dpf = spectral_len > 0 ? (1.0f / (float)spectral_len) * (float)dur : 0.0f;
     for (int i = 0; i < n; i++) {
         float ss = (float)start_offset + ((float)seg4[4 * i + 1] * dpf);           /* :141 */
         float es = (float)start_offset + ((float)seg4[4 * i + 2] * dpf);           /* :142 */

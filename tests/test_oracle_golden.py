@@ -1,0 +1,139 @@
+"""Pins the CPU oracle (oracle/bfa_oracle.c) against golden vectors generated FROM THE REFERENCE
+(tests/golden/make_golden.py).  Integer results and log_softmax bit patterns must be identical;
+confidences go through torch.exp in the reference (MKL VML, not restatable) and are held to 2e-7."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hotpath_cases.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _params(ora, m):
+    return ora.make_params(m["blank"], m["sil"], m["anchors"], m["ignore_noise"], m["truly_forced"], m["boost"],
+                           m["enforce"])
+
+
+def test_decode_alignments_matches_reference(ora, gold):
+    meta = json.loads(str(gold["meta"]))
+    n_seg_mode = n_err = 0
+    for i, m in enumerate(meta):
+        lp, tk = gold[f"c{i}_lp"], gold[f"c{i}_tok"]
+        prm = _params(ora, m)
+        res = ora.decode_alignments(lp[None], tk[None] if tk.size else np.zeros((1, 1), np.int32), [m["T"]], [m["S"]], prm)
+        if m["error"]:
+            assert res["status"][0] == ora.ERR_TOO_SHORT
+            assert "Audio too short" in m["error"]
+            n_err += 1
+            continue
+        assert res["status"][0] == 0, f"case {i}"
+        got = np.array(ora.segments_as_lists(res)[0], np.int32).reshape(-1, 4)
+        np.testing.assert_array_equal(got, gold[f"c{i}_seg"], err_msg=f"case {i} {m}")
+        if m["S"] > 0:
+            np.testing.assert_array_equal(res["frame_ph"][0, :m["T"]], gold[f"c{i}_fph"], err_msg=f"case {i}")
+            np.testing.assert_array_equal(res["frame_idx"][0, :m["T"]], gold[f"c{i}_fidx"], err_msg=f"case {i}")
+            n_seg_mode += int(res["mode"][0] == ora.MODE_SEGMENTED)
+            score = ora.alignment_score(lp, res["frame_ph"][0, :m["T"]])
+            assert abs(score - m["score"]) <= 1e-9 * max(1.0, abs(m["score"]))
+    assert n_seg_mode >= 6 and n_err == 1
+
+
+def test_modified_log_probs_bit_exact(ora, gold):
+    """boost + log_softmax + floor (forced_alignment.py:29-83) reproduce torch's float32 bits."""
+    meta = json.loads(str(gold["meta"]))
+    checked = 0
+    for i, m in enumerate(meta):
+        key = f"c{i}_mod"
+        if key not in gold.files:
+            continue
+        rc, mod = ora.prepare_emissions(gold[f"c{i}_lp"], gold[f"c{i}_tok"], _params(ora, m))
+        assert rc == 0
+        assert (mod.view(np.int32) == gold[key].view(np.int32)).all(), f"case {i}"
+        sil = ora.detect_silence(mod, 0, 0.9, max(m["anchors"], 1))
+        np.testing.assert_array_equal(np.array(sil, np.int32).reshape(-1, 2), gold[f"c{i}_sil09"])
+        checked += 1
+    assert checked >= 20
+
+
+def test_log_softmax_bit_exact(ora, gold):
+    for C in (67, 17):
+        got = ora.log_softmax_rows(gold[f"ls{C}_in"])
+        assert (got.view(np.int32) == gold[f"ls{C}_out"].view(np.int32)).all()
+
+
+def test_simple_mode_matches_reference(ora, gold):
+    meta = json.loads(str(gold["meta"]))
+    n = 0
+    for i, m in enumerate(meta):
+        key = f"c{i}_simple"
+        if key not in gold.files:
+            continue
+        prm = ora.make_params(m["blank"], m["sil"], m["anchors"], m["ignore_noise"], m["truly_forced"], False, False)
+        res = ora.decode_alignments(gold[f"c{i}_lp"][None], gold[f"c{i}_tok"][None], [m["T"]], [m["S"]], prm, simple=True)
+        got = np.array(ora.segments_as_lists(res)[0], np.int32).reshape(-1, 4)
+        np.testing.assert_array_equal(got, gold[key], err_msg=f"case {i}")
+        n += 1
+    assert n >= 30
+
+
+def test_viterbi_direct(ora, gold):
+    vmeta = json.loads(str(gold["vmeta"]))
+    for i, m in enumerate(vmeta):
+        path = gold[f"v{i}_path"]
+        rc, fph, fidx, _, _ = ora.viterbi(gold[f"v{i}_lp"], path, np.arange(m["L"]) - 1, m["bw"], m["truly_forced"], m["blank"])
+        assert rc == 0
+        np.testing.assert_array_equal(fph, gold[f"v{i}_fph"], err_msg=f"v{i} {m}")
+        np.testing.assert_array_equal(fidx, gold[f"v{i}_fidx"], err_msg=f"v{i} {m}")
+
+
+def test_confidences_and_ms(ora, gold):
+    meta = json.loads(str(gold["meta"]))
+    n = exact = 0
+    for i, m in enumerate(meta):
+        key = f"c{i}_conf"
+        if key not in gold.files:
+            continue
+        fs = [tuple(r) for r in gold[f"c{i}_conf_in"]]
+        rc, conf, st, en = ora.confidences(gold[f"c{i}_lp"], fs)
+        assert rc == 0
+        np.testing.assert_allclose(conf, gold[key], atol=2e-7, rtol=0)
+        np.testing.assert_array_equal(np.stack([st, en], 1), gold[f"c{i}_conf_se"])
+        n += len(fs)
+        exact += int((conf == gold[key]).sum())
+        segs = [(f[0], int(s), int(e), f[3]) for f, s, e in zip(fs, st, en)]
+        a, b = ora.convert_to_ms(segs, m["T"], 0.25, m["T"] * 268, 16000)
+        np.testing.assert_array_equal(np.stack([a, b], 1), gold[f"c{i}_ms"])
+    assert n > 500 and exact > 0.8 * n
+
+
+def test_level2_postprocessing(ora, gold):
+    """core.py:925-956 on synthetic logits: ensure_target_coverage (default), extend_soft_boundaries_func,
+    confidences, ms, sort -- the reference's 8-tuples are reproduced from the oracle's stages."""
+    lc, lg = gold["l2_logits_class"], gold["l2_logits_group"]
+    B = lc.shape[0]
+    for head, logits, toks, blank in (("p", lc, gold["l2_tokens"], 66), ("g", lg, gold["l2_group_tokens"], 16)):
+        lp = np.stack([ora.log_softmax_rows(logits[b]) for b in range(B)])
+        prm = ora.make_params(blank, 0)
+        res = ora.decode_alignments(lp, toks, gold["l2_spectral_lens"], gold["l2_seq_lens"], prm)
+        assert (res["status"] == 0).all()
+        for b in range(B):
+            segs = ora.segments_as_lists(res)[b]
+            segs = ora.ensure_target_coverage_default(segs, int(gold["l2_seq_lens"][b]))
+            segs = ora.extend_soft_boundaries(lp[b], segs, 3)
+            rc, conf, st, en = ora.confidences(lp[b], segs)
+            assert rc == 0
+            segs = [(s[0], int(a), int(e), s[3]) for s, a, e in zip(segs, st, en)]
+            sm, em = ora.convert_to_ms(segs, int(gold["l2_spectral_lens"][b]), 0.5 * b, int(gold["l2_wav_lens"][b]), 16000)
+            order = np.argsort(sm, kind="stable")
+            gi, gf = gold[f"l2_{head}{b}_int"], gold[f"l2_{head}{b}_flt"]
+            got_int = np.array([[segs[k][0], segs[k][1], segs[k][2], segs[k][3], 0] for k in order], np.int32).reshape(-1, 5)
+            np.testing.assert_array_equal(got_int, gi, err_msg=f"head {head} item {b}")
+            np.testing.assert_allclose(conf[order], gf[:, 0], atol=2e-7, rtol=0)
+            np.testing.assert_array_equal(sm[order], gf[:, 1])
+            np.testing.assert_array_equal(em[order], gf[:, 2])
