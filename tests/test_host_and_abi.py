@@ -1,0 +1,162 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/bfa.h declares, the host
+logic of the Python mirror, the no-GPU failure mode, and the world_size-2 gather on gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "bfa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(bfa_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bournemouth_forced_aligner_amd import _lib
+    assert os.path.exists(_lib.SO_PATH), "build it first: python __graft_entry__.py"
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/bfa.h but not exported"
+    assert set(_lib.EXPORTS) <= set(names)
+    lib.bfa_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.bfa_version()
+    assert lib.bfa_abi_version() == 1
+
+
+def test_params_default_and_workspace_query():
+    from bournemouth_forced_aligner_amd import _lib
+    lib = _lib.lib()
+    p = _lib.BfaParams()
+    lib.bfa_params_default(ctypes.byref(p), 66, 0)
+    assert (p.blank_id, p.silence_id, p.silence_anchors, p.ignore_noise, p.truly_forced, p.boost_targets,
+            p.enforce_minimum, p.simple, p.max_blanks) == (66, 0, 10, 1, 1, 1, 1, 0, 10)
+    small = lib.bfa_workspace_bytes(256, 600, 20, 67, ctypes.byref(p))
+    big = lib.bfa_workspace_bytes(4096, 1000, 40, 67, ctypes.byref(p))
+    assert 0 < small < big < 2 * 1024 ** 3
+    p.silence_anchors = 0
+    assert lib.bfa_workspace_bytes(4096, 1000, 40, 67, ctypes.byref(p)) < big
+    assert lib.bfa_workspace_bytes(0, 1000, 40, 67, ctypes.byref(p)) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the failure mode on a machine without a GPU")
+def test_no_gpu_fails_loudly_no_cpu_fallback():
+    from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+    h = ctypes.c_void_p()
+    assert _lib.lib().bfa_create(ctypes.byref(h), 0) == _lib.BFA_ERR_NO_DEVICE
+    au = AlignmentUtils(66, 0)
+    lp = torch.zeros((1, 10, 67))
+    with pytest.raises(RuntimeError, match="no CPU implementation|needs an AMD GPU"):
+        au.decode_alignments(lp, torch.tensor([[3, 4]]), torch.tensor([10]), torch.tensor([2]))
+
+
+def test_argument_errors_match_reference():
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    au = AlignmentUtils(66, 0)
+    with pytest.raises(ValueError, match="Phoneme sequences and lengths required for forced alignment"):
+        au.decode_alignments(torch.zeros((1, 4, 67)))  # forced_alignment.py:878-879
+    au.viterbi_decoder.set_blank_id(None)
+    with pytest.raises(ValueError, match="Blank ID not set"):
+        au.viterbi_decoder._params(True, True, True)  # forced_alignment.py:104-105
+
+
+def test_assort_frames_host_rule(ora):
+    from bournemouth_forced_aligner_amd import ViterbiDecoder
+    rng = np.random.default_rng(3)
+    for ign in (True, False):
+        vd = ViterbiDecoder(66, 0, ignore_noise=ign)
+        for _ in range(50):
+            n = int(rng.integers(1, 80))
+            ph = rng.choice([66, 66, 66, 5, 9], size=n)
+            ix = np.where(ph == 66, -1, rng.integers(0, 3, size=n))
+            reps = rng.integers(1, 14, size=n)
+            ph, ix = np.repeat(ph, reps)[:200], np.repeat(ix, reps)[:200]
+            got = vd.assort_frames(torch.from_numpy(ph), torch.from_numpy(ix))
+            assert got == ora.assort_frames(ph, ix, 66, ign, 10)
+    assert ViterbiDecoder(66, 0).assort_frames([], []) == []
+
+
+def test_convert_to_ms_modes():
+    from bournemouth_forced_aligner_amd import convert_to_ms
+    fs = [(5, 10, 20, 0, False, 0.5), (7, 20, 31, 1, False, 0.25)]
+    a = convert_to_ms(fs, 100, 0.5, 26800, 16000)               # python ints: float64 arithmetic
+    assert a[0][6] == (0.5 + 10 * ((26800 / 16000) / 100)) * 1000
+    b = convert_to_ms(fs, torch.tensor(100), 0.5, 26800, 16000)  # 0-dim tensor: float32 arithmetic (core.py:941)
+    f32 = np.float32
+    dpf = (f32(1) / f32(100)) * f32(26800 / 16000)
+    assert b[1][7] == float((f32(0.5) + f32(31) * dpf) * f32(1000))
+    assert len(convert_to_ms([(1, 2, 3)], 10, 0.0, 1600, 16000)[0]) == 8
+
+
+def test_class_mask_hint():
+    from bournemouth_forced_aligner_amd import ViterbiDecoder
+    vd = ViterbiDecoder(66, 0, silence_anchors=10)
+    assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False) == 0b10          # L=161 -> R=3
+    assert vd.class_mask_hint([600], [20], has_sil=False) == 0b1                     # L=81  -> R=2
+    assert vd.class_mask_hint([1000], [40], has_sil=True) == 0b11                    # segments may be shorter
+    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False) == 0b10001       # L=481 -> R=8, L=33 -> R=2
+
+
+def test_lpt_sharding_is_a_partition_and_balanced():
+    from bournemouth_forced_aligner_amd.sharding import shard_utterances, utterance_cost
+    rng = np.random.default_rng(0)
+    T = rng.integers(200, 3001, size=4096)
+    S = np.maximum(1, T // 25)
+    shards = shard_utterances(T, S, 8)
+    allidx = np.sort(np.concatenate(shards))
+    np.testing.assert_array_equal(allidx, np.arange(4096))
+    loads = np.array([utterance_cost(T[s], S[s]).sum() for s in shards], np.float64)
+    assert loads.max() / loads.mean() < 1.01
+
+
+def _gloo_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from bournemouth_forced_aligner_amd.sharding import gather_results, shard_utterances
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    n = 37
+    T = rng.integers(50, 400, size=n)
+    S = np.maximum(1, T // 25)
+    cap = int(S.max()) + 2
+    segs = rng.integers(0, 500, size=(n, cap, 4)).astype(np.int32)
+    cnt = rng.integers(0, cap + 1, size=n).astype(np.int32)
+    conf = rng.random((n, cap)).astype(np.float32)
+    shards = shard_utterances(T, S, world)
+    mine = shards[rank]
+    local_cap = int(S[mine].max()) + 2  # ranks may use different capacities
+    out = gather_results(torch.from_numpy(segs[mine][:, :local_cap]), torch.from_numpy(np.minimum(cnt[mine], local_cap)),
+                         torch.from_numpy(conf[mine][:, :local_cap]), torch.from_numpy(mine), n, dst=0)
+    if rank == 0:
+        gs, gc, gf = out
+        ok = True
+        for i in range(n):
+            r = next(k for k in range(world) if i in shards[k])
+            lc = int(S[shards[r]].max()) + 2
+            c = min(int(cnt[i]), lc)
+            ok &= int(gc[i]) == c
+            ok &= bool((gs[i, :c].numpy() == segs[i, :c]).all())
+            ok &= bool((gf[i, :c].numpy() == conf[i, :c]).all())
+        open(os.path.join(tmp, "ok"), "w").write("1" if ok else "0")
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gather_on_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), "ok")).read() == "1"
