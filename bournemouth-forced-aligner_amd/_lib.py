@@ -15,7 +15,8 @@ MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
            "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
-           "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect"]
+           "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
+           "bfa_prepare_emissions"]
 
 
 class BfaParams(ctypes.Structure):
@@ -64,6 +65,8 @@ def lib():
     L.bfa_workspace_bytes.restype = sz
     L.bfa_align_batch.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(BfaParams),
                                   vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
+    L.bfa_prepare_emissions.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(BfaParams),
+                                        vp, i64, i64, vp, sz, vp]
     L.bfa_confidences.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]
     L.bfa_postprocess.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]
     L.bfa_log_softmax.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]

@@ -15,6 +15,7 @@
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
+extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                                       int C, void *stream);
 extern "C" int bfa_launch_postprocess(const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
@@ -245,6 +246,36 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     }
     const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                          const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
+                          const bfa_params *params, float *out, int64_t out_strideB, int64_t out_strideT,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!logp || !tokens || !S_len || !params || !out || !workspace) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (B <= 0 || Tmax <= 0 || Smax <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
+    if (C != 67 && C != 17) return fail(h, BFA_ERR_UNSUPPORTED, "bfa_prepare_emissions supports C = 67 and C = 17");
+    const Layout l = layout_for(B, Tmax, Smax, params);
+    bfa::AlignArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const uintptr_t basep = (uintptr_t)workspace;
+    const uintptr_t aligned = (basep + 255) & ~(uintptr_t)255;
+    Carve c((void *)aligned);
+    const size_t need = carve_all(c, B, Tmax, Smax, params, l, &a, true) + (aligned - basep);
+    if (need > workspace_bytes) return fail(h, BFA_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
+    a.logp = logp; a.strideB = strideB; a.strideT = strideT;
+    a.B = B; a.Tmax = Tmax; a.C = C; a.Smax = Smax;
+    a.T_len = T_len; a.tokens = tokens; a.S_len = S_len;
+    a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = 0;
+    a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = 1; a.p.max_blanks = 10;
+    // k_plan also writes seg_count/status: point them at scratch
+    a.seg_count = a.uS; a.status = a.umode; a.seg_cap = 1;
+    a.seg_count = (int32_t *)a.frame_ph; a.status = (int32_t *)a.frame_idx;
+    const int rc = bfa_launch_prepare(&a, out, out_strideB, out_strideT, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, rc < 0 ? "unsupported width" : hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }
 

@@ -1,3 +1,5 @@
-// K1 instantiation for posterior widths C <= 32 (see bfa_dp.inc)
+// K1 instantiation for posterior widths C <= 32 (see bfa_dp.inc); C == 17 takes the bfa_dp3.inc hot path
 #define BFA_NK 2
+#define BFA_DP3_NFULL 1
+#define BFA_DP3_TAIL 1
 #include "bfa_dp.inc"

@@ -349,6 +349,24 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     return (int)hipGetLastError();
 }
 
+extern "C" int bfa_launch_prepare_nk2(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, hipStream_t stream);
+extern "C" int bfa_launch_prepare_nk5(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, hipStream_t stream);
+
+// emission preparation only (forced_alignment.py:121-129): k_plan for the target masks, then the block kernel
+extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream_)
+{
+    using namespace bfa;
+    hipStream_t stream = (hipStream_t)stream_;
+    const AlignArgs &a = *args;
+    (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
+    hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
+    int done = 0;
+    if (a.C <= 32) done = bfa_launch_prepare_nk2(&a, out, oB, oT, stream);
+    else if (a.C <= 80) done = bfa_launch_prepare_nk5(&a, out, oB, oT, stream);
+    if (!done) return -1;
+    return (int)hipGetLastError();
+}
+
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream_)
 {
     using namespace bfa;

@@ -207,6 +207,34 @@ class ViterbiDecoder:
         res._keepalive = (lp, toks, ws)
         return res
 
+    def prepare_emissions(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True):
+        """The reference's `modified_log_probs` (forced_alignment.py:121-129: _boost_target_phonemes then
+        _enforce_minimum_probabilities) for a batch, as a device tensor [B,T,C] (rows beyond pred_lens are zero)."""
+        dev = _device_of(log_probs)
+        lp = log_probs.to(device=dev, dtype=torch.float32)
+        if lp.stride(2) != 1:
+            lp = lp.contiguous()
+        B, Tmax, C = lp.shape
+        toks = _as_i32(true_seqs, dev)
+        if toks.dim() == 1:
+            toks = toks.unsqueeze(0)
+        Smax = max(1, toks.shape[1])
+        S_len = _as_i32(true_seqs_lens, dev)
+        T_len = _as_i32(pred_lens, dev)
+        params = self._params(boost_targets, enforce_minimum, False)
+        L = _lib.lib()
+        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+        ws = self._ws.get(L.bfa_workspace_bytes(B, Tmax, Smax, C, ctypes.byref(params)), dev)
+        out = torch.zeros_like(lp)
+        with torch.cuda.device(dev):
+            rc = L.bfa_prepare_emissions(h, lp.data_ptr(), lp.stride(0), lp.stride(1), B, Tmax, C,
+                                         T_len.data_ptr() if T_len is not None else None, toks.data_ptr(),
+                                         S_len.data_ptr(), Smax, ctypes.byref(params), out.data_ptr(), out.stride(0),
+                                         out.stride(1), ws.data_ptr(), ws.numel(),
+                                         torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, h, "bfa_prepare_emissions")
+        return out
+
     def decode_with_forced_alignment(self, log_probs, true_sequence, return_scores=False, boost_targets=True,
                                      enforce_minimum=True, anchor_pauses=True, debug=False):
         """forced_alignment.py:87-199 for one utterance: log_probs [T, C], true_sequence [S].

@@ -119,6 +119,17 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
                     int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The prepared emissions the DP consumes -- the reference's `modified_log_probs`
+ * (forced_alignment.py:121-129: _boost_target_phonemes + _enforce_minimum_probabilities) -- written to
+ * out[b*out_strideB + t*out_strideT + c] for t < T_len[b].  Bit-identical to the reference's float32 values.
+ * Same workspace as bfa_align_batch.  C = 67 (ph66 head) and C = 17 (group head).
+ */
+int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                          const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
+                          const bfa_params *params, float *out, int64_t out_strideB, int64_t out_strideT,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * utils._calculate_confidences (utils.py:70-113) for a whole batch, including the reference's
  * in-place aliasing of probs[start, phoneme].  logp is the ORIGINAL (un-boosted) matrix; T_rows[b]
  * is log_probs.shape[0] of item b as the reference passes it (the padded Tmax, core.py:936).

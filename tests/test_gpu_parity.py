@@ -181,3 +181,23 @@ def test_segmented_mode_group_head_and_flags(ora, gpu_device):
     _compare(res, exp, T_len)
     res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 17, anchors=10, boost=False, enf=True, ign=False)
     _compare(res, exp, T_len)
+
+
+@pytest.mark.parametrize("C", [67, 17])
+def test_prepared_emissions_bit_exact(ora, gpu_device, C):
+    """DP-level pin: the boosted / normalised / floored emissions (forced_alignment.py:121-129) the HIP path
+    feeds its DP are bit-identical to the oracle's (which is bit-identical to torch's, see the golden tests)."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    rng = np.random.default_rng(600 + C)
+    lp, tk, T_len, S_len = _mk_batch(rng, 24, C, (5, 300), (1, 60), peak=float(rng.choice([9.0, 2.0, 0.5])), sigma=2.0)
+    lp[3] *= 8.0  # widen the dynamic range: exp underflow / denormal results
+    au = AlignmentUtils(C - 1, 0)
+    for boost, enf in ((True, True), (True, False), (False, True)):
+        got = au.viterbi_decoder.prepare_emissions(torch.from_numpy(lp).to(gpu_device), torch.from_numpy(tk), T_len,
+                                                   S_len, boost_targets=boost, enforce_minimum=enf).cpu().numpy()
+        prm = ora.make_params(C - 1, 0, 10, True, True, boost, enf)
+        for b in range(lp.shape[0]):
+            T, S = int(T_len[b]), int(S_len[b])
+            rc, want = ora.prepare_emissions(lp[b, :T], tk[b, :S], prm)
+            assert rc == 0
+            assert (got[b, :T].view(np.int32) == want.view(np.int32)).all(), f"item {b} boost={boost} enf={enf}"
