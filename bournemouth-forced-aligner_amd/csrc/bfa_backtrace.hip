@@ -96,7 +96,6 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
 
             const int t = t0 + lane;    // this lane's frame
             const int qrow = ((t >> 2) - q0) * W;
-            const int fsh = 8 * (t & 3);
             const bool mine = t < t1;
             int my_state = 0;
             int t_hi = t1 - 1;          // frames (.., t_hi] still to be labelled in this chunk
@@ -104,8 +103,11 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
                 // backpointer code of this lane's frame for the CURRENT state (state[t-1] = s - k at frame t)
                 uint32_t k = 0;
                 if (mine && t <= t_hi && t > 0) {
+                    // pair (A,B) of (frame t&3, slot sr) in dword sr>>2 (layout: DpCore in bfa_dp3.inc / bfa_dp.inc)
                     const uint32_t wd = sbp[(qrow + (sr >> 2)) * nl + sl];
-                    k = (wd >> (fsh + 2 * (sr & 3))) & 3u;
+                    const int Rw = min(4, R - 4 * (sr >> 2));
+                    const uint32_t code = (wd >> (2 * (4 * Rw - 1 - ((t & 3) * Rw + (sr & 3))))) & 3u;
+                    k = (code >= 2u) ? code - 1u : 0u; // A ? (B ? 2 : 1) : 0
                 }
                 const unsigned long long mv = __ballot(k != 0);
                 if (mv == 0) { // the path stays in s down to the chunk start
