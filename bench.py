@@ -54,6 +54,17 @@ def synth_batch(B, T, S, C, seed, device, peak=9.0):
     return lp, toks.to(torch.int32)
 
 
+def synth_ragged(B, Tlo, Thi, C, seed, device, peak=9.0):
+    """BASELINE.json configs[3] shape: T ~ U{Tlo..Thi}, S = max(1, T // 25), padded to Thi / max S."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    T_len = torch.randint(Tlo, Thi + 1, (B,), generator=g)
+    S_len = torch.clamp(T_len // 25, min=1)
+    Tmax, Smax = int(T_len.max()), int(S_len.max())
+    lp, toks = synth_batch(B, Tmax, Smax, C, seed, device, peak=peak)  # planted path of the padded shape ...
+    return lp, toks, T_len.to(torch.int32), S_len.to(torch.int32)        # ... truncated per utterance by the lengths
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,8 +74,10 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--tokens", type=int, default=40)
     ap.add_argument("--classes", type=int, default=67)
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="utterances timed on the host oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="utterances timed on the host oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ragged", action="store_true",
+                    help="side measurement: mixed-length batch T~U{200..3000}, S=T//25 (BASELINE.json configs[3] per-GPU shard)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,6 +98,8 @@ def main():
 
     B, T, S, C = args.batch, args.frames, args.tokens, args.classes
     blank, sil = C - 1, 0
+    if args.ragged:
+        return ragged_main(args, dev, rank, world)
     # two distinct batches so consecutive steps never stream the same 1.1 GB (> the 256 MB Infinity Cache anyway)
     bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev) for i in range(2)]
     T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -156,26 +171,40 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu and args.cpu_sample > 0:
         from oracle import oracle as ora
-        n = min(args.cpu_sample, B)
-        lp_h = bufs[0][0][:n].cpu().numpy()
-        tk_h = bufs[0][1][:n].cpu().numpy()
         prm = ora.make_params(blank, sil)
-        ora.decode_alignments(lp_h[:4], tk_h[:4], [T] * 4, [S] * 4, prm, seg_cap=S + 2)  # warm
-        w0 = time.perf_counter()
-        exp = ora.decode_alignments(lp_h, tk_h, [T] * n, [S] * n, prm, seg_cap=S + 2)
-        w = time.perf_counter() - w0
-        cpu = {"value": n * T / w, "unit": "aligned frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} utterances of T={T} S={S} C={C} (same synthetic batch), oracle/bfa_oracle.c single thread, {w:.1f} s"}
-        # the bench doubles as a full-size parity check on that sample
-        got = res if (args.steps % 2 == 1) else step(0)
-        torch.cuda.synchronize()
-        gs = got.segs[:n].cpu().numpy()
-        gc = got.seg_count[:n].cpu().numpy()
-        mism = int((gc != exp["seg_count"]).sum())
-        for b in range(n):
-            if gc[b] == exp["seg_count"][b] and not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all():
-                mism += 1
-        cpu["parity_mismatching_utterances"] = mism
+        per = min(args.cpu_sample, B)
+        nbuf = max(1, min(len(bufs), (args.cpu_sample + B - 1) // B))
+        lp_w = bufs[0][0][:4].cpu().numpy()
+        ora.decode_alignments(lp_w, bufs[0][1][:4].cpu().numpy(), [T] * 4, [S] * 4, prm, seg_cap=S + 2)  # warm
+        w = 0.0
+        n_total = 0
+        mism = 0
+        for bi in range(nbuf):
+            lp_h = bufs[bi][0][:per].cpu().numpy()
+            tk_h = bufs[bi][1][:per].cpu().numpy()
+            w0 = time.perf_counter()
+            exp = ora.decode_alignments(lp_h, tk_h, [T] * per, [S] * per, prm, seg_cap=S + 2)
+            w += time.perf_counter() - w0
+            n_total += per
+            # the bench doubles as a full-size parity check on that sample
+            got = step(bi)
+            torch.cuda.synchronize()
+            gs = got.segs[:per].cpu().numpy()
+            gc = got.seg_count[:per].cpu().numpy()
+            for b in range(per):
+                if gc[b] != exp["seg_count"][b] or not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all():
+                    mism += 1
+        cpu = {"value": n_total * T / w, "unit": "aligned frames/s", "cores": 1, "kind": "port",
+               "sample": f"{n_total} utterances of T={T} S={S} C={C} (the bench batches themselves), "
+                         f"oracle/bfa_oracle.c single thread, {w:.1f} s",
+               "parity_mismatching_utterances": mism}
+
+    # HBM bytes of one K1 launch from the PMC passes of tools/profile.sh (committed under profiles/), if it was
+    # taken on this workload; FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_k1_traffic.json")
+    if os.path.exists(tpath) and (B, T, S, C) == (4096, 1000, 40, 67):
+        traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
 
     if rank == 0:
         line = {
@@ -187,7 +216,9 @@ def main():
                                    f"(boost+floor+truly_forced, anchors=10, no SIL in targets -> standard mode)",
                        "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "bytes per K1 launch (rocprofv3 PMC, profiles/r01_k1_traffic.json)",
+                         "algorithmic_bytes_per_launch": frames_per_step * bytes_per_frame,
                          "kernel": "k_dp (K1 banded Viterbi forward)", "kernel_ms": k1_ms,
                          "algorithmic_bytes_per_frame": bytes_per_frame},
             "cpu_baseline": cpu,
@@ -197,6 +228,36 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ragged_main(args, dev, rank, world):
+    """Not the headline line: throughput and parity sample on a mixed-length shard (prints its own JSON)."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    from oracle import oracle as ora
+    C, B = args.classes, args.batch
+    lp, tk, T_len, S_len = synth_ragged(B, 200, 3000, C, 1004 + rank, dev)
+    au = AlignmentUtils(blank_id=C - 1, silence_id=0)
+    hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False)
+    Td, Sd = T_len.to(dev), S_len.to(dev)
+    for _ in range(2):
+        res = au.decode_alignments_device(lp, tk, Td, Sd, class_mask=hint)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = au.decode_alignments_device(lp, tk, Td, Sd, class_mask=hint)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.steps
+    frames = int(T_len.sum())
+    n = min(96, B)
+    exp = ora.decode_alignments(lp[:n].cpu().numpy(), tk[:n].cpu().numpy(), T_len[:n].numpy(), S_len[:n].numpy(),
+                                ora.make_params(C - 1, 0), seg_cap=res.segs.shape[1])
+    gs, gc = res.segs[:n].cpu().numpy(), res.seg_count[:n].cpu().numpy()
+    mism = sum(int(gc[b] != exp["seg_count"][b] or not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all()) for b in range(n))
+    if rank == 0:
+        print(json.dumps({"workload": f"ragged batch={B} T~U[200,3000] S=T//25 C={C}", "frames": frames,
+                          "ms_per_step": el * 1e3, "frames_per_s": frames / el,
+                          "parity_sample": n, "parity_mismatching_utterances": mism,
+                          "status_ok": bool((res.status.cpu() == 0).all())}))
 
 
 if __name__ == "__main__":
