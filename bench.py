@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+NO_WINDOW = False
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -76,9 +77,12 @@ def main():
     ap.add_argument("--classes", type=int, default=67)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="utterances timed on the host oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-window", action="store_true", help="A/B: full state layout instead of the sliding window")
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: mixed-length batch T~U{200..3000}, S=T//25 (BASELINE.json configs[3] per-GPU shard)")
     args = ap.parse_args()
+    global NO_WINDOW
+    NO_WINDOW = bool(args.no_window)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +114,7 @@ def main():
 
     # the lengths are known on the host (constant here), and the synthetic targets never contain SIL:
     # tell the library which K1 register class occurs so that it does not launch the empty ones
-    hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False)
+    hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False, n_classes=(None if NO_WINDOW else C))
 
     def step(i):
         lp, tk = bufs[i % 2]
@@ -237,7 +241,7 @@ def ragged_main(args, dev, rank, world):
     C, B = args.classes, args.batch
     lp, tk, T_len, S_len = synth_ragged(B, 200, 3000, C, 1004 + rank, dev)
     au = AlignmentUtils(blank_id=C - 1, silence_id=0)
-    hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False)
+    hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=(None if NO_WINDOW else C))
     Td, Sd = T_len.to(dev), S_len.to(dev)
     for _ in range(2):
         res = au.decode_alignments_device(lp, tk, Td, Sd, class_mask=hint)

@@ -60,11 +60,16 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
         }
         if (it.kind != ITEM_DP) continue;
 
-        const int R = r_class_for_L(it.L);
+        // window items (Item::win = Rw): [nq] window bases, then [quad][64 lanes] dwords; lane l, slot r of quad q
+        // holds state base[q] + l*Rw + r (DpCoreW in bfa_dp3.inc)
+        const bool win = it.win > 0;
+        const int R = win ? it.win : r_class_for_L(it.L);
         const int W = bp_words_for_R(R);
         const int Ts = it.Ts, L = it.L;
-        const int nl = bp_lanes(L, R);
-        const uint32_t *bp = a.bp + it.bp_off;
+        const int nl = win ? 64 : bp_lanes(L, R);
+        const uint32_t *bp_base = a.bp + it.bp_off;
+        const uint32_t *bp = bp_base + (win ? ((Ts + 3) >> 2) : 0);
+        const int invR = 65536 / R + 1; // (d * invR) >> 16 == d / R for the d < 64*R + 8 that occur (R <= 4)
         int s = it.final_state;          // wave-uniform walk state
         int sl = s / R, sr = s - sl * R; // its (lane, register slot)
         // chunk = CQ quads (4*CQ frames, <= 64) = CQ*W*nl <= 1024 dwords, i.e. <= 16 dwords per lane
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
             const int t = t0 + lane;    // this lane's frame
             const int qrow = ((t >> 2) - q0) * W;
             const bool mine = t < t1;
+            const int wbase = (win && mine) ? (int)bp_base[t >> 2] : 0; // window base of this lane's quad
             int my_state = 0;
             int t_hi = t1 - 1;          // frames (.., t_hi] still to be labelled in this chunk
             while (t_hi >= t0) {
@@ -104,10 +110,19 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
                 uint32_t k = 0;
                 if (mine && t <= t_hi && t > 0) {
                     // pair (A,B) of (frame t&3, slot sr) in dword sr>>2 (layout: DpCore in bfa_dp3.inc / bfa_dp.inc)
-                    const uint32_t wd = sbp[(qrow + (sr >> 2)) * nl + sl];
-                    const int Rw = min(4, R - 4 * (sr >> 2));
-                    const uint32_t code = (wd >> (2 * (4 * Rw - 1 - ((t & 3) * Rw + (sr & 3))))) & 3u;
-                    k = (code >= 2u) ? code - 1u : 0u; // A ? (B ? 2 : 1) : 0
+                    int xl = sl, xr = sr;
+                    bool inw = true;
+                    if (win) { // a frame at which s lies outside the window is below the next move: its code is not used
+                        const int d = s - wbase;
+                        inw = d >= 0 && d < 64 * R;
+                        xl = (d * invR) >> 16; xr = d - xl * R;
+                    }
+                    if (inw) {
+                        const uint32_t wd = sbp[(qrow + (xr >> 2)) * nl + xl];
+                        const int Rw = min(4, R - 4 * (xr >> 2));
+                        const uint32_t code = (wd >> (2 * (4 * Rw - 1 - ((t & 3) * Rw + (xr & 3))))) & 3u;
+                        k = (code >= 2u) ? code - 1u : 0u; // A ? (B ? 2 : 1) : 0
+                    }
                 }
                 const unsigned long long mv = __ballot(k != 0);
                 if (mv == 0) { // the path stays in s down to the chunk start

@@ -65,7 +65,7 @@ Layout layout_for(int B, int Tmax, int Smax, const bfa_params *p)
     l.item_cap = B + (seg ? B * nseg_max : 0);
     const int R = bfa::r_class_for_L(Lmax);
     const int64_t quads = (Tmax + 3) / 4 + (seg ? 3 * (int64_t)(Smax / 2 + 2) : 0);
-    if (R > 0) l.bp_per_utt = quads * bfa::bp_words_for_R(R) * 64;
+    if (R > 0) l.bp_per_utt = quads * bfa::bp_words_for_R(R) * 64 + quads;
     else l.bp_per_utt = quads * 4 * ((Lmax + 15) / 16);
     return l;
 }
@@ -231,7 +231,7 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     a.p.ignore_noise = params->ignore_noise; a.p.truly_forced = params->truly_forced;
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = params->simple;
     a.p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
-    a.p.class_mask = (uint32_t)params->reserved[0];
+    a.p.class_mask = (uint32_t)params->reserved[0]; a.p.win_mask = 0;
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
     // one wavefront per work item; surplus items are taken by the blocks' stride loops
@@ -271,6 +271,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
     a.T_len = T_len; a.tokens = tokens; a.S_len = S_len;
     a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = 0;
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = 1; a.p.max_blanks = 10;
+    a.p.class_mask = 0; a.p.win_mask = 0;
     // k_plan also writes seg_count/status: point them at scratch
     a.seg_count = a.uS; a.status = a.umode; a.seg_cap = 1;
     a.seg_count = (int32_t *)a.frame_ph; a.status = (int32_t *)a.frame_idx;

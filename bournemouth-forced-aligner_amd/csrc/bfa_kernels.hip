@@ -68,7 +68,7 @@ __global__ void k_plan(AlignArgs a)
 
     Item it;
     it.kind = ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = T; it.tok0 = 0; it.nt = S; it.stride = 0; it.L = 0;
-    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = 0; it.anch_off = -1;
+    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = 0; it.anch_off = -1; it.win = 0; it.pad_ = 0;
     it.bp_off = (int64_t)b * a.bp_per_utt;
     int mode = BFA_MODE_EMPTY;
 
@@ -104,6 +104,8 @@ __global__ void k_plan(AlignArgs a)
             it.kind = ITEM_DP;
             it.bw = band_standard(L);
             mode = BFA_MODE_STANDARD;
+            const int rw = win_class_for(L, it.bw); // band narrow enough for the sliding-window consumer?
+            if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
         }
         if (seg_candidate && status == BFA_ITEM_OK) { // k_plan_segmented decides (it may keep this fallback)
             mode = -1 - mode;
@@ -328,18 +330,28 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
-    const AlignArgs &a = *args;
+    AlignArgs a = *args;
     const DevParams &p = a.p;
     const int nk = (a.C + 15) / 16;
+    // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
+    const int Lmax = 4 * a.Smax + 1;
+    unsigned mask = r_class_mask_upto(Lmax);
+    if (p.class_mask) mask &= p.class_mask;
+    const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0;
+    const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
+    // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
+    unsigned wmask = 0;
+    if (mode != 2 && (a.C == 67 || a.C == 17) && Lmax > 60) {
+        const int rw_top = (2 * (Lmax / 4) + 3 + WIN_MARGIN + 63) / 64;
+        wmask = (rw_top >= 4) ? 15u : ((1u << rw_top) - 1u);
+        if (p.class_mask) wmask &= (p.class_mask >> 8);
+    }
+    a.p.win_mask = wmask;
+    mask |= wmask << 8;
     (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
     hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
     if (!p.simple && p.anchors > 0 && p.sil >= 0) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
-    // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
-    unsigned mask = r_class_mask_upto(4 * a.Smax + 1);
-    if (p.class_mask) mask &= p.class_mask;
-    const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0;
-    const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, stream);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, stream);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, stream);

@@ -38,11 +38,14 @@ struct Item {
     int32_t final_state;
     int32_t anch_off;  // >= 0: offset of this DP's per-row silence-anchor counts in the utterance's pool; -1: none
     int64_t bp_off;    // dword offset of this item's backpointer block in the workspace
+    int32_t win;       // > 0: K1 used the sliding in-band state window with `win` states per lane (bp: window layout)
+    int32_t pad_;
 };
 
 struct DevParams {
     int32_t blank, sil, anchors, ignore_noise, truly_forced, boost, enforce, simple, max_blanks;
     uint32_t class_mask; // K1 classes to launch (host hint), 0 = derive from the shapes
+    uint32_t win_mask;   // sliding-window classes the planner may use (bit Rw-1), set by bfa_launch_align
 };
 
 // everything the kernels of one bfa_align_batch call need; passed by value
@@ -106,6 +109,24 @@ __host__ __device__ inline unsigned r_class_bit(int R)
     case 8: return 16u; case 12: return 32u; case 16: return 64u; default: return 0u;
     }
 }
+// ---- sliding in-band window (K1 consumer, standard-mode items with an active band) ----------------
+// The reference masks every state outside [t*pace - bw, t*pace + bw] to -1000 after each frame
+// (forced_alignment.py:650-653).  With emissions <= 0, whenever the final score is above the sentinel the traced
+// path never leaves the band, so only the in-band states need computing: a window of 64*Rw consecutive states
+// that slides with the band.  Rw = states per lane of the window, 0 = not applicable (keep the full layout).
+constexpr int WIN_MARGIN = 10; // states of slack besides the 2*bw+1 band states and the 2 below-band predecessors
+__host__ __device__ inline int win_class_for(int L, int bw)
+{
+    if (bw <= 0) return 0;
+    const int need = 2 * bw + 1 + 2 + WIN_MARGIN;
+    const int rw = (need + 63) / 64;
+    const int rfull = r_class_for_L(L);
+    if (rfull == 0 || rw >= rfull || rw > 4) return 0;
+    return rw;
+}
+// window class bits in the class mask: bit 8 + (Rw-1)
+__host__ __device__ inline unsigned win_class_bit(int rw) { return (rw >= 1 && rw <= 4) ? (1u << (7 + rw)) : 0u; }
+
 // all classes up to and including the class of L
 __host__ __device__ inline unsigned r_class_mask_upto(int L)
 {
@@ -124,7 +145,7 @@ __host__ __device__ inline int64_t bp_dwords(int Ts, int L)
 {
     const int R = r_class_for_L(L);
     const int64_t quads = (Ts + 3) / 4;
-    if (R > 0) return quads * bp_words_for_R(R) * bp_lanes(L, R);
+    if (R > 0) return quads * bp_words_for_R(R) * bp_lanes(L, R) + quads; // + room for the window layout's per-quad base
     return (int64_t)Ts * ((L + 15) / 16); // big-L kernel: 2 bits per state, row-major
 }
 

@@ -131,12 +131,32 @@ class ViterbiDecoder:
                 return i
         return None
 
-    def class_mask_hint(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False):
-        """Optional host-side hint for bfa_params.reserved[0]: the K1 states-per-lane classes that occur
-        in this batch, from HOST copies of the lengths.  `has_sil` says whether any target may contain the
-        silence id (then the segmented mode can create shorter DPs, and every class up to the largest is
-        kept).  Without a hint the library launches every class the tensor shapes allow."""
+    _WIN_MARGIN = 10  # bfa_types.hpp WIN_MARGIN
+
+    @classmethod
+    def _win_class(cls, L):
+        """Sliding-window class (states per lane) the planner picks for a standard-mode DP of L states, or 0
+        (bfa_types.hpp win_class_for)."""
+        bw = max(L // 4, 20) if L > 60 else 0
+        if bw <= 0:
+            return 0
+        rw = (2 * bw + 3 + cls._WIN_MARGIN + 63) // 64
+        full = cls._r_class(L)
+        if full is None or rw >= (2, 3, 4, 6, 8, 12, 16)[full] or rw > 4:
+            return 0
+        return rw
+
+    def class_mask_hint(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
+                        boost_targets=True, enforce_minimum=True):
+        """Optional host-side hint for bfa_params.reserved[0]: the K1 kernel classes that occur in this batch,
+        from HOST copies of the lengths.  Bits 0-6: full-layout states-per-lane classes {2,3,4,6,8,12,16};
+        bits 8-11: sliding-window classes Rw = 1..4 (used for standard-mode DPs whose band is narrower than
+        the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`).
+        `has_sil` says whether any target may contain the silence id (then the segmented mode can create
+        shorter DPs, and every full class up to the largest is kept).  Without a hint the library launches
+        every class the tensor shapes allow."""
         mask, top = 0, -1
+        window_ok = (n_classes in (67, 17)) and boost_targets and enforce_minimum and not simple
         for T, S in zip(T_lens, S_lens):
             T, S = int(T), int(S)
             if S <= 0:
@@ -153,10 +173,15 @@ class ViterbiDecoder:
                 for s2 in (3, 2, 1):
                     if stride * S + 1 > T:
                         stride = s2
-            c = self._r_class(stride * S + 1)
+            L = stride * S + 1
+            c = self._r_class(L)
             if c is None:
                 continue
-            mask |= 1 << c
+            rw = self._win_class(L) if (window_ok and L <= T) else 0
+            if rw:
+                mask |= 1 << (7 + rw)  # the rare sentinel rerun of a window item needs no hint bit
+            else:
+                mask |= 1 << c
             top = max(top, self._r_class(4 * S + 1) or 6)
         if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and top >= 0:
             mask |= (1 << (top + 1)) - 1

@@ -79,6 +79,63 @@ def test_standard_mode_parity(ora, gpu_device, C, peak):
         _compare(res, exp, T_len)
 
 
+@pytest.mark.parametrize("C", [67, 17])
+def test_sliding_window_classes(ora, gpu_device, C):
+    """Standard-mode DPs whose band is narrower than the path run in the sliding-window consumer (Rw = 1..4,
+    bfa_dp3.inc DpCoreW); sharp posteriors stay above the sentinel, flat ones end at it and are redone with the
+    full layout.  Both must reproduce the oracle, for T from just above L (pace ~ 1) to T >> L."""
+    rng = np.random.default_rng(4200 + C)
+    blank = C - 1
+    lps, toks = [], []
+    for S in (15, 16, 20, 25, 26, 33, 40, 47, 48, 60, 63, 64, 90, 120, 121):   # L = 4S+1: window classes 1,2,3,4 and none
+        for T in (4 * S + 1, 4 * S + 2, 4 * S + 9, 5 * S + 3, 8 * S, 25 * S):
+            for peak in (9.0, 3.0, 0.3):
+                lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=peak, sigma=1.0, repeat_rate=0.15)
+                lps.append(lp)
+                toks.append(tk)
+    for lo in range(0, len(lps), 90):
+        lp, tk, T_len, S_len = cases.pad_batch(lps[lo:lo + 90], toks[lo:lo + 90], C, blank)
+        for tf in (True, False):
+            res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=0, tf=tf)
+            _compare(res, exp, T_len)
+
+
+def test_sliding_window_equals_full_layout(gpu_device):
+    """The same batch through the window classes (hint bits 8-11) and through the full-layout classes only."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    rng = np.random.default_rng(77)
+    C, blank = 67, 66
+    lps, toks = [], []
+    for _ in range(64):
+        S = int(rng.integers(15, 121))
+        T = int(rng.integers(4 * S + 1, 30 * S))
+        lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=float(rng.choice([9.0, 2.0, 0.5])), sigma=1.0,
+                                       repeat_rate=0.1)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+    au = AlignmentUtils(blank, 0, silence_anchors=0)
+    vd = au.viterbi_decoder
+    h_win = vd.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=C)
+    h_full = vd.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False)
+    assert h_win >> 8 and not (h_full >> 8)
+    lpd = torch.from_numpy(lp).to(gpu_device)
+    out = []
+    for h in (h_win, h_full, 0):
+        r = vd.align_batch(lpd, torch.from_numpy(tk), T_len, S_len, anchor_pauses=False, class_mask=h)
+        torch.cuda.synchronize()
+        out.append((r.frame_phonemes.cpu().numpy(), r.frame_phonemes_idx.cpu().numpy(), r.segs.cpu().numpy(),
+                    r.seg_count.cpu().numpy()))
+    for k in (1, 2):
+        cnt = out[0][3]
+        np.testing.assert_array_equal(cnt, out[k][3])
+        for b in range(len(cnt)):
+            T = int(T_len[b])
+            np.testing.assert_array_equal(out[0][0][b, :T], out[k][0][b, :T])
+            np.testing.assert_array_equal(out[0][1][b, :T], out[k][1][b, :T])
+            np.testing.assert_array_equal(out[0][2][b, :cnt[b]], out[k][2][b, :cnt[b]])
+
+
 def test_ignore_noise_false_and_given_emissions(ora, gpu_device):
     rng = np.random.default_rng(5)
     lp, tk, T_len, S_len = _mk_batch(rng, 32, 67, (30, 300), (1, 40), peak=6.0)
