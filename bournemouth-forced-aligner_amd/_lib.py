@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbfa_hip.so")
+# BFA_HIP_LIBRARY selects another build of the same ABI (kernel experiments under tools/ubench)
+SO_PATH = os.environ.get("BFA_HIP_LIBRARY") or os.path.join(_HERE, "libbfa_hip.so")
 
 BFA_OK = 0
 BFA_ERR_INVALID_ARGUMENT, BFA_ERR_NO_DEVICE, BFA_ERR_LAUNCH = -1, -2, -3
