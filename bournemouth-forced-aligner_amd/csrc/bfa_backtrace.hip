@@ -6,6 +6,11 @@
 // step per frame, all 64 lanes look at 64 consecutive frames at once for the CURRENT state, a ballot
 // finds the latest frame with a move, every frame above it takes the current state, the state is
 // updated and the search continues below that frame: ~ (#moves + T/64) wave steps per utterance.
+//
+// Every wave of the launch is resident at once and a walk step is a short dependent chain
+// (LDS gather -> extract -> ballot -> readlane), so the kernel time is (steps x step latency) of one
+// utterance: the walk is instantiated per backpointer layout (states per lane, window or full) so that the
+// per-step address and shift arithmetic folds into a handful of instructions.
 #include <hip/hip_runtime.h>
 
 #include "bfa_math.hpp"
@@ -20,9 +25,136 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Backpointer layouts (written by DpCore / DpCoreW in bfa_dp3.inc and k_dp in bfa_dp.inc):
+//   full   : rows of 4 frames, W = ceil(R/4) dwords per lane and row, lanes < nl = ceil(L/R); dword w of lane l
+//            holds slots 4w..4w+3 (Rsub of them), pair (frame f, slot r) at bits 2*(4*Rsub-1-(f*Rsub+(r&3))).
+//   window : [nrows] window bases, then rows of FPW = win_frames_per_word(R) frames, one dword per lane, 64 lanes;
+//            lane l, slot r of a row holds state base[row] + l*R + r, pair (f, r) at bits 2*(FPW*R-1-(f*R+r)).
+// code = (A<<1)|B with A = (c0 < best), B = (c1 < best): k = A ? (B ? 2 : 1) : 0 = max(code,1) - 1.
+template <int R, bool WIN>
+__device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, uint32_t *sbp, int lane)
+{
+    constexpr int W = WIN ? 1 : (R + 3) / 4;
+    constexpr int FPW = WIN ? (R == 1 ? 16 : R == 2 ? 8 : 4) : 4;
+    constexpr int FSH = (FPW == 16) ? 4 : (FPW == 8) ? 3 : 2;
+    constexpr int CQ = WIN ? 64 / FPW : 16 / W; // rows per chunk
+    constexpr int CF = CQ * FPW;                // frames per chunk (<= 64)
+    constexpr int NDW = WIN ? CQ : 16;          // dwords per lane and chunk
+    constexpr int NPRE = 3;                     // chunks in flight in registers
+    const DevParams &p = a.p;
+    const int b = it.utt;
+    int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
+    int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
+    const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
+    const int Ts = it.Ts, L = it.L;
+    const int nrows = (Ts + FPW - 1) >> FSH;
+    const int nl = WIN ? 64 : bp_lanes(L, R);
+    const uint32_t *bp_base = a.bp + it.bp_off;
+    const uint32_t *bp = bp_base + (WIN ? nrows : 0);
+    const int inv_stride = 65536 / it.stride + 1; // (d * inv) >> 16 == d / stride for d < 1100, stride <= 4
+    int s = it.final_state;                       // wave-uniform walk state
+    int sl = s / R, sr = s - sl * R;              // full layout: its (lane, register slot)
+    const int nchunks = (Ts + CF - 1) / CF;
+
+    uint32_t pre[NPRE][NDW];
+    auto fetch = [&](uint32_t (&dst)[NDW], int c) {
+        const int q0 = c * CQ;
+        const int q1 = min(nrows, q0 + CQ);
+        const int ndw = (q1 - q0) * W * nl;
+        const uint32_t *src = bp + (int64_t)q0 * W * nl;
+#pragma unroll
+        for (int d = 0; d < NDW; ++d) {
+            const int idx = d * 64 + lane;
+            dst[d] = (c >= 0 && idx < ndw) ? src[idx] : 0u;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) fetch(pre[k], nchunks - 1 - k);
+
+    // one chunk: stage its dwords in LDS, refill the register buffer with the chunk NPRE further down, walk
+    auto walk_chunk = [&](uint32_t (&buf)[NDW], int c) {
+        const int t0 = c * CF;
+        const int t1 = min(Ts, t0 + CF);
+        wave_sync_lds();
+#pragma unroll
+        for (int d = 0; d < NDW; ++d) sbp[d * 64 + lane] = buf[d];
+        wave_sync_lds();
+        fetch(buf, c - NPRE);
+
+        const int t = t0 + lane; // this lane's frame
+        const int row = (t >> FSH) - (t0 >> FSH);
+        const int fw = t & (FPW - 1); // frame within its row
+        const bool mine = t < t1;
+        const bool can_move = mine && t > 0;
+        int my_state = 0;
+        int t_hi = t1 - 1; // frames (.., t_hi] still to be labelled in this chunk
+        // per-lane constants of the gather
+        int wbase = 0, rowoff, sh0;
+        if (WIN) {
+            if (mine) wbase = (int)bp_base[t >> FSH]; // window base of this lane's row
+            rowoff = row * 64;
+            sh0 = 2 * (FPW * R - 1 - fw * R);
+        } else {
+            rowoff = row * W * nl;
+            sh0 = 0;
+        }
+        while (t_hi >= t0) {
+            // backpointer code of this lane's frame for the CURRENT state (state[t-1] = s - k at frame t)
+            uint32_t code = 0;
+            if (WIN) {
+                // a frame at which s lies outside the window is below the next move: its code is not used
+                const int d = s - wbase;
+                const int dc = min(max(d, 0), 64 * R - 1);
+                const int xl = dc / R, xr = dc - xl * R;
+                const uint32_t wd = sbp[rowoff + xl];
+                code = ((unsigned)d < (unsigned)(64 * R)) ? ((wd >> (sh0 - 2 * xr)) & 3u) : 0u;
+            } else {
+                const int w = sr >> 2;                  // wave-uniform
+                const int rsub = min(4, R - 4 * w);     // slots in dword w
+                const uint32_t wd = sbp[rowoff + w * nl + sl];
+                code = (wd >> (2 * (4 * rsub - 1 - (fw * rsub + (sr & 3))))) & 3u;
+            }
+            const uint32_t k = (can_move && t <= t_hi) ? (max(code, 1u) - 1u) : 0u;
+            const unsigned long long mv = __ballot(k != 0);
+            if (mv == 0) { // the path stays in s down to the chunk start
+                if (t <= t_hi) my_state = s;
+                break;
+            }
+            const int jl = 63 - __builtin_clzll(mv); // latest frame (lane) at which the path moves
+            if (t <= t_hi && lane >= jl) my_state = s;
+            const int kk = (int)__builtin_amdgcn_readlane((int)k, jl);
+            s -= kk;
+            if (!WIN) {
+                sr -= kk;
+                while (sr < 0) { sr += R; sl -= 1; }
+            }
+            if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap (:692)
+            t_hi = t0 + jl - 1;
+        }
+        if (mine) {
+            const int o = t - it.pad_left; // :447-448 trim the boundary padding
+            if (o >= 0 && o < it.nout) {
+                int ph = p.blank, id = -1;
+                if (my_state >= 1) {
+                    const int q = ((my_state - 1) * inv_stride) >> 16;
+                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
+                }
+                oph[it.out0 + o] = ph;
+                oid[it.out0 + o] = id;
+            }
+        }
+    };
+    // the register buffers keep their roles (no copies, which would wait for the loads in flight)
+    for (int cg = nchunks - 1; cg >= 0; cg -= NPRE) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+            if (cg - k >= 0) walk_chunk(pre[k], cg - k);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
 {
-    __shared__ uint32_t sbp[16 * 64]; // one chunk: (16/W) quads x W x (nl <= 64) dwords
+    __shared__ uint32_t sbp[16 * 64]; // one chunk: <= 1024 dwords
     const int lane = threadIdx.x & 63;
     const DevParams &p = a.p;
     const int n_items = a.counters[0];
@@ -59,96 +191,22 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
             continue;
         }
         if (it.kind != ITEM_DP) continue;
-
-        // window items (Item::win = Rw): [nq] window bases, then [quad][64 lanes] dwords; lane l, slot r of quad q
-        // holds state base[q] + l*Rw + r (DpCoreW in bfa_dp3.inc)
-        const bool win = it.win > 0;
-        const int R = win ? it.win : r_class_for_L(it.L);
-        const int W = bp_words_for_R(R);
-        const int Ts = it.Ts, L = it.L;
-        const int nl = win ? 64 : bp_lanes(L, R);
-        const uint32_t *bp_base = a.bp + it.bp_off;
-        const uint32_t *bp = bp_base + (win ? ((Ts + 3) >> 2) : 0);
-        const int invR = 65536 / R + 1; // (d * invR) >> 16 == d / R for the d < 64*R + 8 that occur (R <= 4)
-        int s = it.final_state;          // wave-uniform walk state
-        int sl = s / R, sr = s - sl * R; // its (lane, register slot)
-        // chunk = CQ quads (4*CQ frames, <= 64) = CQ*W*nl <= 1024 dwords, i.e. <= 16 dwords per lane
-        const int CQ = 16 / W;
-        const int CF = 4 * CQ;
-        const int nchunks = (Ts + CF - 1) / CF;
-        uint32_t pre[16]; // next chunk, in flight in registers while the current one is walked
-        auto fetch = [&](int c) {
-            const int q0 = c * CQ;
-            const int q1 = min((Ts + 3) >> 2, q0 + CQ);
-            const int ndw = (q1 - q0) * W * nl;
-            const uint32_t *src = bp + (int64_t)q0 * W * nl;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                const int idx = d * 64 + lane;
-                pre[d] = (idx < ndw) ? src[idx] : 0u;
+        if (it.win > 0) {
+            switch (it.win) {
+            case 1: walk_item<1, true>(a, it, sbp, lane); break;
+            case 2: walk_item<2, true>(a, it, sbp, lane); break;
+            case 3: walk_item<3, true>(a, it, sbp, lane); break;
+            default: walk_item<4, true>(a, it, sbp, lane); break;
             }
-        };
-        fetch(nchunks - 1);
-        for (int c = nchunks - 1; c >= 0; --c) {
-            const int t0 = c * CF;
-            const int t1 = min(Ts, t0 + CF);
-            const int q0 = t0 >> 2;
-            wave_sync_lds();
-#pragma unroll
-            for (int d = 0; d < 16; ++d) sbp[d * 64 + lane] = pre[d];
-            wave_sync_lds();
-            if (c > 0) fetch(c - 1);
-
-            const int t = t0 + lane;    // this lane's frame
-            const int qrow = ((t >> 2) - q0) * W;
-            const bool mine = t < t1;
-            const int wbase = (win && mine) ? (int)bp_base[t >> 2] : 0; // window base of this lane's quad
-            int my_state = 0;
-            int t_hi = t1 - 1;          // frames (.., t_hi] still to be labelled in this chunk
-            while (t_hi >= t0) {
-                // backpointer code of this lane's frame for the CURRENT state (state[t-1] = s - k at frame t)
-                uint32_t k = 0;
-                if (mine && t <= t_hi && t > 0) {
-                    // pair (A,B) of (frame t&3, slot sr) in dword sr>>2 (layout: DpCore in bfa_dp3.inc / bfa_dp.inc)
-                    int xl = sl, xr = sr;
-                    bool inw = true;
-                    if (win) { // a frame at which s lies outside the window is below the next move: its code is not used
-                        const int d = s - wbase;
-                        inw = d >= 0 && d < 64 * R;
-                        xl = (d * invR) >> 16; xr = d - xl * R;
-                    }
-                    if (inw) {
-                        const uint32_t wd = sbp[(qrow + (xr >> 2)) * nl + xl];
-                        const int Rw = min(4, R - 4 * (xr >> 2));
-                        const uint32_t code = (wd >> (2 * (4 * Rw - 1 - ((t & 3) * Rw + (xr & 3))))) & 3u;
-                        k = (code >= 2u) ? code - 1u : 0u; // A ? (B ? 2 : 1) : 0
-                    }
-                }
-                const unsigned long long mv = __ballot(k != 0);
-                if (mv == 0) { // the path stays in s down to the chunk start
-                    if (mine && t <= t_hi) my_state = s;
-                    t_hi = t0 - 1;
-                    break;
-                }
-                const int jl = 63 - __builtin_clzll(mv); // latest frame (lane) at which the path moves
-                if (mine && t <= t_hi && lane >= jl) my_state = s;
-                const int kk = (int)__builtin_amdgcn_readlane((int)k, jl);
-                s -= kk; sr -= kk;
-                while (sr < 0) { sr += R; sl -= 1; }
-                if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap (:692)
-                t_hi = t0 + jl - 1;
-            }
-            if (mine) {
-                const int o = t - it.pad_left; // :447-448 trim the boundary padding
-                if (o >= 0 && o < it.nout) {
-                    int ph = p.blank, id = -1;
-                    if (my_state >= 1) {
-                        const int q = (my_state - 1) / it.stride;
-                        if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
-                    }
-                    oph[it.out0 + o] = ph;
-                    oid[it.out0 + o] = id;
-                }
+        } else {
+            switch (r_class_for_L(it.L)) {
+            case 2: walk_item<2, false>(a, it, sbp, lane); break;
+            case 3: walk_item<3, false>(a, it, sbp, lane); break;
+            case 4: walk_item<4, false>(a, it, sbp, lane); break;
+            case 6: walk_item<6, false>(a, it, sbp, lane); break;
+            case 8: walk_item<8, false>(a, it, sbp, lane); break;
+            case 12: walk_item<12, false>(a, it, sbp, lane); break;
+            default: walk_item<16, false>(a, it, sbp, lane); break;
             }
         }
     }

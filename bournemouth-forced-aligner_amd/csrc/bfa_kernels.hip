@@ -342,8 +342,11 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
     unsigned wmask = 0;
     if (mode != 2 && (a.C == 67 || a.C == 17) && Lmax > 60) {
-        const int rw_top = (2 * (Lmax / 4) + 3 + WIN_MARGIN + 63) / 64;
-        wmask = (rw_top >= 4) ? 15u : ((1u << rw_top) - 1u);
+        wmask = 15u; // Rw = 1..4; classes no utterance can use cost one empty launch each (narrow with the hint)
+        for (int rw = 4; rw >= 1; --rw) { // drop the classes above the one the longest possible path would take
+            const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20);
+            if (top > 0 && rw > top) wmask &= ~(1u << (rw - 1));
+        }
         if (p.class_mask) wmask &= (p.class_mask >> 8);
     }
     a.p.win_mask = wmask;

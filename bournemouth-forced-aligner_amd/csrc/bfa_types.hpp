@@ -114,15 +114,19 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // (forced_alignment.py:650-653).  With emissions <= 0, whenever the final score is above the sentinel the traced
 // path never leaves the band, so only the in-band states need computing: a window of 64*Rw consecutive states
 // that slides with the band.  Rw = states per lane of the window, 0 = not applicable (keep the full layout).
-constexpr int WIN_MARGIN = 10; // states of slack besides the 2*bw+1 band states and the 2 below-band predecessors
+// Sliding-window consumer (DpCoreW): 64*Rw states follow the band.  A lane's backpointer dword covers
+// win_frames_per_word(Rw) frames (2 bits x Rw slots per frame) and the window only moves between dwords, so it must
+// hold the band of all those frames: the 2*bw+1 in-band states + the band's advance over the dword (pace <= 1) +
+// the two below-band predecessor states + the lane granularity of the move + 1 of slack.
+__host__ __device__ inline int win_frames_per_word(int rw) { return rw == 1 ? 16 : (rw == 2 ? 8 : 4); }
 __host__ __device__ inline int win_class_for(int L, int bw)
 {
     if (bw <= 0) return 0;
-    const int need = 2 * bw + 1 + 2 + WIN_MARGIN;
-    const int rw = (need + 63) / 64;
     const int rfull = r_class_for_L(L);
-    if (rfull == 0 || rw >= rfull || rw > 4) return 0;
-    return rw;
+    if (rfull == 0) return 0;
+    for (int rw = 1; rw <= 4 && rw < rfull; ++rw)
+        if (2 * bw + 1 + win_frames_per_word(rw) + 2 + rw + 1 <= 64 * rw) return rw;
+    return 0;
 }
 // window class bits in the class mask: bit 8 + (Rw-1)
 __host__ __device__ inline unsigned win_class_bit(int rw) { return (rw >= 1 && rw <= 4) ? (1u << (7 + rw)) : 0u; }

@@ -131,20 +131,22 @@ class ViterbiDecoder:
                 return i
         return None
 
-    _WIN_MARGIN = 10  # bfa_types.hpp WIN_MARGIN
-
     @classmethod
     def _win_class(cls, L):
         """Sliding-window class (states per lane) the planner picks for a standard-mode DP of L states, or 0
         (bfa_types.hpp win_class_for)."""
         bw = max(L // 4, 20) if L > 60 else 0
-        if bw <= 0:
-            return 0
-        rw = (2 * bw + 3 + cls._WIN_MARGIN + 63) // 64
         full = cls._r_class(L)
-        if full is None or rw >= (2, 3, 4, 6, 8, 12, 16)[full] or rw > 4:
+        if bw <= 0 or full is None:
             return 0
-        return rw
+        rfull = (2, 3, 4, 6, 8, 12, 16)[full]
+        for rw in (1, 2, 3, 4):
+            if rw >= rfull:
+                break
+            frames_per_word = {1: 16, 2: 8}.get(rw, 4)
+            if 2 * bw + 1 + frames_per_word + 2 + rw + 1 <= 64 * rw:
+                return rw
+        return 0
 
     def class_mask_hint(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
                         boost_targets=True, enforce_minimum=True):
