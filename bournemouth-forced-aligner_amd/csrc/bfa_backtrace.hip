@@ -32,7 +32,7 @@ __device__ __forceinline__ void wave_sync_lds()
 //            lane l, slot r of a row holds state base[row] + l*R + r, pair (f, r) at bits 2*(FPW*R-1-(f*R+r)).
 // code = (A<<1)|B with A = (c0 < best), B = (c1 < best): k = A ? (B ? 2 : 1) : 0 = max(code,1) - 1.
 template <int R, bool WIN>
-__device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, uint32_t *sbp, int lane)
+__device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, uint32_t *sbp, int32_t *stok, int lane)
 {
     constexpr int W = WIN ? 1 : (R + 3) / 4;
     constexpr int FPW = WIN ? (R == 1 ? 16 : R == 2 ? 8 : 4) : 4;
@@ -56,8 +56,12 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
     int sl = s / R, sr = s - sl * R;              // full layout: its (lane, register slot)
     const int nchunks = (Ts + CF - 1) / CF;
 
-    uint32_t pre[NPRE][NDW];
-    auto fetch = [&](uint32_t (&dst)[NDW], int c) {
+    // the item's tokens go to LDS: a global gather per chunk would sit between the backpointer loads in flight
+    // and the stores, and waiting for it (vmcnt counts in order) would wait for all of them
+    for (int j = lane; j < it.nt; j += 64) stok[j] = tok[j];
+
+    uint32_t pre[NPRE][NDW + 1]; // + the window base of this lane's row (loaded with the chunk, not at its use)
+    auto fetch = [&](uint32_t (&dst)[NDW + 1], int c) {
         const int q0 = c * CQ;
         const int q1 = min(nrows, q0 + CQ);
         const int ndw = (q1 - q0) * W * nl;
@@ -67,18 +71,21 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
             const int idx = d * 64 + lane;
             dst[d] = (c >= 0 && idx < ndw) ? src[idx] : 0u;
         }
+        const int tl = c * CF + lane;
+        dst[NDW] = (WIN && c >= 0 && tl < Ts) ? bp_base[tl >> FSH] : 0u;
     };
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) fetch(pre[k], nchunks - 1 - k);
 
     // one chunk: stage its dwords in LDS, refill the register buffer with the chunk NPRE further down, walk
-    auto walk_chunk = [&](uint32_t (&buf)[NDW], int c) {
+    auto walk_chunk = [&](uint32_t (&buf)[NDW + 1], int c) {
         const int t0 = c * CF;
         const int t1 = min(Ts, t0 + CF);
         wave_sync_lds();
 #pragma unroll
         for (int d = 0; d < NDW; ++d) sbp[d * 64 + lane] = buf[d];
         wave_sync_lds();
+        const int wbase = (int)buf[NDW]; // window base of this lane's row
         fetch(buf, c - NPRE);
 
         const int t = t0 + lane; // this lane's frame
@@ -89,9 +96,8 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
         int my_state = 0;
         int t_hi = t1 - 1; // frames (.., t_hi] still to be labelled in this chunk
         // per-lane constants of the gather
-        int wbase = 0, rowoff, sh0;
+        int rowoff, sh0;
         if (WIN) {
-            if (mine) wbase = (int)bp_base[t >> FSH]; // window base of this lane's row
             rowoff = row * 64;
             sh0 = 2 * (FPW * R - 1 - fw * R);
         } else {
@@ -137,7 +143,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
                 int ph = p.blank, id = -1;
                 if (my_state >= 1) {
                     const int q = ((my_state - 1) * inv_stride) >> 16;
-                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
+                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = stok[q]; id = it.tok0 + q; }
                 }
                 oph[it.out0 + o] = ph;
                 oid[it.out0 + o] = id;
@@ -155,6 +161,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
 __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
 {
     __shared__ uint32_t sbp[16 * 64]; // one chunk: <= 1024 dwords
+    __shared__ int32_t stok[1024];    // the item's tokens (nt <= L <= 1024)
     const int lane = threadIdx.x & 63;
     const DevParams &p = a.p;
     const int n_items = a.counters[0];
@@ -193,20 +200,20 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
         if (it.kind != ITEM_DP) continue;
         if (it.win > 0) {
             switch (it.win) {
-            case 1: walk_item<1, true>(a, it, sbp, lane); break;
-            case 2: walk_item<2, true>(a, it, sbp, lane); break;
-            case 3: walk_item<3, true>(a, it, sbp, lane); break;
-            default: walk_item<4, true>(a, it, sbp, lane); break;
+            case 1: walk_item<1, true>(a, it, sbp, stok, lane); break;
+            case 2: walk_item<2, true>(a, it, sbp, stok, lane); break;
+            case 3: walk_item<3, true>(a, it, sbp, stok, lane); break;
+            default: walk_item<4, true>(a, it, sbp, stok, lane); break;
             }
         } else {
             switch (r_class_for_L(it.L)) {
-            case 2: walk_item<2, false>(a, it, sbp, lane); break;
-            case 3: walk_item<3, false>(a, it, sbp, lane); break;
-            case 4: walk_item<4, false>(a, it, sbp, lane); break;
-            case 6: walk_item<6, false>(a, it, sbp, lane); break;
-            case 8: walk_item<8, false>(a, it, sbp, lane); break;
-            case 12: walk_item<12, false>(a, it, sbp, lane); break;
-            default: walk_item<16, false>(a, it, sbp, lane); break;
+            case 2: walk_item<2, false>(a, it, sbp, stok, lane); break;
+            case 3: walk_item<3, false>(a, it, sbp, stok, lane); break;
+            case 4: walk_item<4, false>(a, it, sbp, stok, lane); break;
+            case 6: walk_item<6, false>(a, it, sbp, stok, lane); break;
+            case 8: walk_item<8, false>(a, it, sbp, stok, lane); break;
+            case 12: walk_item<12, false>(a, it, sbp, stok, lane); break;
+            default: walk_item<16, false>(a, it, sbp, stok, lane); break;
             }
         }
     }

@@ -28,17 +28,18 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // =================================================================================================
-// k_plan : one thread per utterance
+// k_plan : sixteen lanes per utterance scan its tokens (coalesced, 16 at a time), lane 0 of the group plans
 // =================================================================================================
 __device__ __forceinline__ int band_standard(int L) { return (L > 60) ? ((L / 4 > 20) ? L / 4 : 20) : 0; } // :190, :976
 
-__global__ void k_plan(AlignArgs a)
+__global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gid >> 4, sub = gid & 15;
     // counters[] are zeroed by a memset node ahead of this kernel; one item slot per utterance, the
     // segmented planner appends more
-    if (b == 0) a.counters[0] = a.B;
-    if (b >= a.B) return;
+    if (gid == 0) a.counters[0] = a.B;
+    if (b >= a.B) return; // whole 16-lane groups
     const DevParams &p = a.p;
     const int Traw = a.T_len ? a.T_len[b] : a.Tmax;
     int T = Traw;
@@ -47,22 +48,31 @@ __global__ void k_plan(AlignArgs a)
     int S = a.S_len[b];
     if (S > a.Smax) S = a.Smax;
     if (S < 0) S = 0;
-    a.uT[b] = T;
-    a.uS[b] = S;
 
     uint32_t m[MASK_WORDS];
 #pragma unroll
     for (int w = 0; w < MASK_WORDS; ++w) m[w] = 0u;
-    int status = BFA_ITEM_OK;
-    bool has_sil = false;
+    int flags = 0; // bit 0: bad token, bit 1: the silence id occurs
     const int32_t *tk = a.tokens + (int64_t)b * a.Smax;
-    for (int j = 0; j < S; ++j) {
+    for (int j = sub; j < S; j += 16) {
         const int t = tk[j];
-        if (t < 0 || t >= a.C) { status = BFA_ITEM_BAD_TOKEN; continue; }
-        if (t == p.sil) has_sil = true;
+        if (t < 0 || t >= a.C) { flags |= 1; continue; }
+        if (t == p.sil) flags |= 2;
         if (t == p.blank) continue; // :45
-        m[t >> 5] |= 1u << (t & 31);
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) m[w] |= ((t >> 5) == w) ? (1u << (t & 31)) : 0u;
     }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        flags |= __shfl_xor(flags, off, 16);
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) m[w] |= __shfl_xor(m[w], off, 16);
+    }
+    if (sub != 0) return;
+    a.uT[b] = T;
+    a.uS[b] = S;
+    int status = (flags & 1) ? BFA_ITEM_BAD_TOKEN : BFA_ITEM_OK;
+    const bool has_sil = (flags & 2) != 0;
 #pragma unroll
     for (int w = 0; w < MASK_WORDS; ++w) a.umask[(int64_t)b * MASK_WORDS + w] = m[w];
 
@@ -88,7 +98,9 @@ __global__ void k_plan(AlignArgs a)
         if (T < 1) { status = BFA_ITEM_TOO_SHORT; it.kind = ITEM_FILL_BLANK; }
         else it.kind = ITEM_DP;
     } else {
-        const bool seg_candidate = (p.anchors > 0 && p.sil >= 0 && has_sil);
+        const bool no_sil_hint = (p.class_mask & BFA_HINT_NO_SILENCE_TARGETS) != 0;
+        const bool seg_candidate = (p.anchors > 0 && p.sil >= 0 && has_sil && !no_sil_hint);
+        if (p.anchors > 0 && p.sil >= 0 && has_sil && no_sil_hint) status = BFA_ITEM_BAD_HINT;
         // standard mode (also the fallback of the segmented attempt)
         int stride = 4; // :153-157
         if (stride * S + 1 > T) stride = 3;
@@ -337,7 +349,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const int Lmax = 4 * a.Smax + 1;
     unsigned mask = r_class_mask_upto(Lmax);
     if (p.class_mask) mask &= p.class_mask;
-    const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0;
+    const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0 && !(p.class_mask & BFA_HINT_NO_SILENCE_TARGETS);
     const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
     // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
     unsigned wmask = 0;
@@ -352,8 +364,8 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     a.p.win_mask = wmask;
     mask |= wmask << 8;
     (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
-    hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
-    if (!p.simple && p.anchors > 0 && p.sil >= 0) bfa_launch_segment_plan(&a, stream);
+    hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, stream);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, stream);
@@ -374,7 +386,7 @@ extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_
     hipStream_t stream = (hipStream_t)stream_;
     const AlignArgs &a = *args;
     (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
-    hipLaunchKernelGGL(k_plan, dim3((a.B + 127) / 128), dim3(128), 0, stream, a);
+    hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     int done = 0;
     if (a.C <= 32) done = bfa_launch_prepare_nk2(&a, out, oB, oT, stream);
     else if (a.C <= 80) done = bfa_launch_prepare_nk5(&a, out, oB, oT, stream);

@@ -75,6 +75,8 @@ class AlignmentResult:
                 raise RuntimeError(f"item {b}: CTC path longer than this build supports")
             if st[b] == _lib.ITEM_SEG_OVERFLOW:
                 raise RuntimeError(f"item {b}: more aligned runs than seg_cap")
+            if st[b] == _lib.ITEM_BAD_HINT:
+                raise RuntimeError(f"item {b}: class_mask hint said no target contains the silence id, but this one does")
 
     def to_lists(self):
         """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871)."""
@@ -155,7 +157,8 @@ class ViterbiDecoder:
         bits 8-11: sliding-window classes Rw = 1..4 (used for standard-mode DPs whose band is narrower than
         the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`).
         `has_sil` says whether any target may contain the silence id (then the segmented mode can create
-        shorter DPs, and every full class up to the largest is kept).  Without a hint the library launches
+        shorter DPs, and every full class up to the largest is kept; otherwise bit 16 tells the library to
+        skip the silence planning, and a target that does contain it is reported as ITEM_BAD_HINT).  Without a hint the library launches
         every class the tensor shapes allow."""
         mask, top = 0, -1
         window_ok = (n_classes in (67, 17)) and boost_targets and enforce_minimum and not simple
@@ -187,6 +190,8 @@ class ViterbiDecoder:
             top = max(top, self._r_class(4 * S + 1) or 6)
         if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and top >= 0:
             mask |= (1 << (top + 1)) - 1
+        if not has_sil and mask:
+            mask |= _lib.HINT_NO_SILENCE_TARGETS  # the silence-anchored planning kernels are not launched
         return mask
 
     def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,

@@ -56,6 +56,9 @@ typedef enum {
 #define BFA_ITEM_BAD_TOKEN 2   /* token id outside [0,C) : reference raises IndexError */
 #define BFA_ITEM_TOO_LARGE 3   /* CTC path longer than this build supports */
 #define BFA_ITEM_SEG_OVERFLOW 4 /* more runs than seg_cap: frame outputs are valid, segments truncated */
+#define BFA_ITEM_BAD_HINT 5     /* reserved[0] said BFA_HINT_NO_SILENCE_TARGETS but this target contains silence_id */
+
+#define BFA_HINT_NO_SILENCE_TARGETS (1 << 16)
 
 /* per-utterance decode mode written to out_mode[b] */
 #define BFA_MODE_EMPTY 0        /* S == 0 -> no segments (forced_alignment.py:894-897) */
@@ -75,8 +78,11 @@ typedef struct {
     int32_t enforce_minimum; /* default 1 : floor target columns at log(1e-8) */
     int32_t simple;          /* 1 = decode_alignments_simple semantics (forced_alignment.py:932-987) */
     int32_t max_blanks;      /* assort_frames(max_blanks=10) */
-    int32_t reserved[3];     /* [0] : optional host hint, bit mask of K1 states-per-lane classes
-                                {2,3,4,6,8,12,16} worth launching (0 = derive from the shapes) */
+    int32_t reserved[3];     /* [0] : optional host hint (0 = derive everything from the tensor shapes):
+                                bits 0-6  K1 full-layout states-per-lane classes {2,3,4,6,8,12,16} worth launching,
+                                bits 8-11 K1 sliding-window classes Rw = 1..4 worth launching,
+                                bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
+                                          silence-anchored planning kernels are not launched */
 } bfa_params;
 
 /* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),

@@ -118,7 +118,7 @@ def test_sliding_window_equals_full_layout(gpu_device):
     vd = au.viterbi_decoder
     h_win = vd.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=C)
     h_full = vd.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False)
-    assert h_win >> 8 and not (h_full >> 8)
+    assert (h_win >> 8) & 15 and not ((h_full >> 8) & 15)
     lpd = torch.from_numpy(lp).to(gpu_device)
     out = []
     for h in (h_win, h_full, 0):
@@ -134,6 +134,28 @@ def test_sliding_window_equals_full_layout(gpu_device):
             np.testing.assert_array_equal(out[0][0][b, :T], out[k][0][b, :T])
             np.testing.assert_array_equal(out[0][1][b, :T], out[k][1][b, :T])
             np.testing.assert_array_equal(out[0][2][b, :cnt[b]], out[k][2][b, :cnt[b]])
+
+
+def test_no_silence_hint_is_checked(gpu_device):
+    """BFA_HINT_NO_SILENCE_TARGETS skips the silence planning; a target that contains the silence id then is an
+    error status, not a silently different alignment."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+    rng = np.random.default_rng(5)
+    C, blank = 67, 66
+    lp, tk, _ = cases.planted_case(rng, 300, 12, C=C, blank=blank, peak=9.0, sil_rate=0.0)
+    lp2, tk2, _ = cases.planted_case(rng, 300, 12, C=C, blank=blank, peak=9.0, sil_rate=0.4)
+    assert (tk2 == 0).any()
+    lpb, tkb, T_len, S_len = cases.pad_batch([lp, lp2], [tk, tk2], C, blank)
+    au = AlignmentUtils(blank, 0)
+    hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=C)
+    assert hint & _lib.HINT_NO_SILENCE_TARGETS
+    res = au.viterbi_decoder.align_batch(torch.from_numpy(lpb).to(gpu_device), torch.from_numpy(tkb), T_len, S_len,
+                                         class_mask=hint)
+    torch.cuda.synchronize()
+    st = res.status.cpu().numpy()
+    assert st[0] == _lib.ITEM_OK and st[1] == _lib.ITEM_BAD_HINT
+    with pytest.raises(RuntimeError):
+        res.raise_for_status()
 
 
 def test_ignore_noise_false_and_given_emissions(ora, gpu_device):

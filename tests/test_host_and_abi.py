@@ -100,15 +100,17 @@ def test_convert_to_ms_modes():
 def test_class_mask_hint():
     from bournemouth_forced_aligner_amd import ViterbiDecoder
     vd = ViterbiDecoder(66, 0, silence_anchors=10)
-    assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False) == 0b10          # L=161 -> R=3
-    assert vd.class_mask_hint([600], [20], has_sil=False) == 0b1                     # L=81  -> R=2
-    assert vd.class_mask_hint([1000], [40], has_sil=True) == 0b11                    # segments may be shorter
-    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False) == 0b10001       # L=481 -> R=8, L=33 -> R=2
-    # sliding-window classes (bits 8-11) on the 67-class head: L=161, bw=40 -> 93 states -> Rw=2; L=81, bw=20 -> Rw=1
-    assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False, n_classes=67) == 1 << 9
-    assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=67) == 1 << 8
-    assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=40) == 0b1         # other widths: generic kernel
-    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == (1 << 11) | 0b1  # L=481, bw=120 -> 253 states -> Rw=4
+    NS = 1 << 16   # BFA_HINT_NO_SILENCE_TARGETS
+    assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False) == NS | 0b10          # L=161 -> R=3
+    assert vd.class_mask_hint([600], [20], has_sil=False) == NS | 0b1                     # L=81  -> R=2
+    assert vd.class_mask_hint([1000], [40], has_sil=True) == 0b11                         # segments may be shorter
+    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False) == NS | 0b10001       # L=481 -> R=8, L=33 -> R=2
+    # sliding-window classes (bits 8-11) on the 67-class head: L=161, bw=40 -> Rw=2; L=81, bw=20 -> Rw=1
+    assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False, n_classes=67) == NS | 1 << 9
+    assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=67) == NS | 1 << 8
+    assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=40) == NS | 0b1       # other widths: generic kernel
+    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
+    assert vd.class_mask_hint([], [], has_sil=False) == 0
 
 
 def test_lpt_sharding_is_a_partition_and_balanced():
