@@ -224,7 +224,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes per K1 launch (rocprofv3 PMC, profiles/r01_k1_traffic.json)",
                          "algorithmic_bytes_per_launch": frames_per_step * bytes_per_frame,
-                         "kernel": "k_dp (K1 banded Viterbi forward)", "kernel_ms": k1_ms,
+                         "kernel": "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer; HIP events also span the k_dp4_redo launch)", "kernel_ms": k1_ms,
                          "algorithmic_bytes_per_frame": bytes_per_frame},
             "cpu_baseline": cpu,
             "confidence_pass_ms": conf_ms,

@@ -152,37 +152,52 @@ __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
         bfa_segment *out = a.segs + (int64_t)b * a.seg_cap;
         int count = 0;
         int run_start = 0, run_ph = 0, run_ix = 0; // the open run (wave-uniform)
-        for (int base = 0; base < Tr; base += 64) {
-            const int t = base + lane;
-            const bool in = t < Tr;
-            const int cph = in ? ph[t] : 0, cix = in ? ix[t] : 0;
-            int pph = __shfl_up(cph, 1), pix = __shfl_up(cix, 1);
-            if (lane == 0) { pph = run_ph; pix = run_ix; }
-            const bool is_start = in && (t == 0 || cph != pph || cix != pix); // :798-801
-            const unsigned long long m = __ballot(is_start);
-            // a start at t>0 closes the run that began at the previous start (shuffles stay convergent)
-            const unsigned long long below = m & ((1ull << lane) - 1ull);
-            const int src = below ? (63 - __builtin_clzll(below)) : 0;
-            const int sph = __shfl(cph, src), six = __shfl(cix, src);
-            const int ps = below ? (base + src) : run_start;
-            const int pp = below ? sph : run_ph;
-            const int pi = below ? six : run_ix;
-            const bool closes = is_start && t > 0;
-            bool emit = false;
-            if (closes) {
-                const int len = t - ps;
-                if (pp == p.blank) emit = (!p.ignore_noise) && (len > p.max_blanks); // :819-827
-                else emit = true;                                                    // :830-831
+        // the framewise arrays are read eight 64-frame slices at a time: the slices do not depend on each other,
+        // only the run bookkeeping does, and one load round trip per slice would be the whole kernel time
+        constexpr int U = 8;
+        for (int base0 = 0; base0 < Tr; base0 += 64 * U) {
+            int vph[U], vix[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = base0 + 64 * u + lane;
+                vph[u] = (t < Tr) ? ph[t] : 0;
+                vix[u] = (t < Tr) ? ix[t] : 0;
             }
-            const unsigned long long em = __ballot(emit);
-            if (emit) {
-                const int slot = count + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-                if (slot < a.seg_cap) { bfa_segment sg; sg.phoneme = pp; sg.start = ps; sg.end = t; sg.target_idx = pi; out[slot] = sg; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int base = base0 + 64 * u;
+                if (base >= Tr) break; // wave-uniform
+                const int t = base + lane;
+                const bool in = t < Tr;
+                const int cph = vph[u], cix = vix[u];
+                int pph = __shfl_up(cph, 1), pix = __shfl_up(cix, 1);
+                if (lane == 0) { pph = run_ph; pix = run_ix; }
+                const bool is_start = in && (t == 0 || cph != pph || cix != pix); // :798-801
+                const unsigned long long m = __ballot(is_start);
+                // a start at t>0 closes the run that began at the previous start (shuffles stay convergent)
+                const unsigned long long below = m & ((1ull << lane) - 1ull);
+                const int src = below ? (63 - __builtin_clzll(below)) : 0;
+                const int sph = __shfl(cph, src), six = __shfl(cix, src);
+                const int ps = below ? (base + src) : run_start;
+                const int pp = below ? sph : run_ph;
+                const int pi = below ? six : run_ix;
+                const bool closes = is_start && t > 0;
+                bool emit = false;
+                if (closes) {
+                    const int len = t - ps;
+                    if (pp == p.blank) emit = (!p.ignore_noise) && (len > p.max_blanks); // :819-827
+                    else emit = true;                                                    // :830-831
+                }
+                const unsigned long long em = __ballot(emit);
+                if (emit) {
+                    const int slot = count + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+                    if (slot < a.seg_cap) { bfa_segment sg; sg.phoneme = pp; sg.start = ps; sg.end = t; sg.target_idx = pi; out[slot] = sg; }
+                }
+                count += __builtin_popcountll(em);
+                const int last = m ? (63 - __builtin_clzll(m)) : 0;
+                const int lph = __shfl(cph, last), lix = __shfl(cix, last);
+                if (m) { run_start = base + last; run_ph = lph; run_ix = lix; }
             }
-            count += __builtin_popcountll(em);
-            const int last = m ? (63 - __builtin_clzll(m)) : 0;
-            const int lph = __shfl(cph, last), lix = __shfl(cix, last);
-            if (m) { run_start = base + last; run_ph = lph; run_ix = lix; }
         }
         if (Tr > 0) { // close the final run
             const int len = Tr - run_start;
