@@ -61,18 +61,18 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
     for (int j = lane; j < it.nt; j += 64) stok[j] = tok[j];
 
     uint32_t pre[NPRE][NDW + 1]; // + the window base of this lane's row (loaded with the chunk, not at its use)
+    // Unconditional loads with clamped addresses (a chunk index below 0 re-reads chunk 0, dwords past the chunk
+    // re-read its last one; neither is used): predicated loads sit in their own basic blocks, and the wait before
+    // the LDS staging then degrades to vmcnt(0), i.e. waits for the chunks that were meant to stay in flight.
     auto fetch = [&](uint32_t (&dst)[NDW + 1], int c) {
-        const int q0 = c * CQ;
+        const int q0 = max(c, 0) * CQ;
         const int q1 = min(nrows, q0 + CQ);
         const int ndw = (q1 - q0) * W * nl;
         const uint32_t *src = bp + (int64_t)q0 * W * nl;
 #pragma unroll
-        for (int d = 0; d < NDW; ++d) {
-            const int idx = d * 64 + lane;
-            dst[d] = (c >= 0 && idx < ndw) ? src[idx] : 0u;
-        }
-        const int tl = c * CF + lane;
-        dst[NDW] = (WIN && c >= 0 && tl < Ts) ? bp_base[tl >> FSH] : 0u;
+        for (int d = 0; d < NDW; ++d) dst[d] = src[min(d * 64 + lane, ndw - 1)];
+        if (WIN) dst[NDW] = bp_base[min(max(c, 0) * CF + lane, Ts - 1) >> FSH];
+        else dst[NDW] = 0u;
     };
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) fetch(pre[k], nchunks - 1 - k);
@@ -151,11 +151,15 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
         }
     };
     // the register buffers keep their roles (no copies, which would wait for the loads in flight)
-    for (int cg = nchunks - 1; cg >= 0; cg -= NPRE) {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k)
-            if (cg - k >= 0) walk_chunk(pre[k], cg - k);
+    static_assert(NPRE == 3, "the unrolled group below is written for three buffers");
+    int cg = nchunks - 1;
+    for (; cg >= NPRE - 1; cg -= NPRE) { // no branches around the chunks of a group (see fetch)
+        walk_chunk(pre[0], cg);
+        walk_chunk(pre[1], cg - 1);
+        walk_chunk(pre[2], cg - 2);
     }
+    if (cg >= 0) walk_chunk(pre[0], cg);
+    if (cg >= 1) walk_chunk(pre[1], cg - 1);
 }
 
 __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
