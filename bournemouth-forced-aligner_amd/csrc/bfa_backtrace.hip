@@ -162,6 +162,62 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
     if (cg >= 1) walk_chunk(pre[1], cg - 1);
 }
 
+// Paths of more than 1024 states (k_dp_big): backpointers row-major, [frame][ng = ceil(L/16)] dwords, dword g =
+// states 16g..16g+15, 2 bits each.  Same ballot-jump walk; every lane keeps the dword of its frame for the current
+// state's group and reloads it when the walk enters another group (every <= 16 moves).
+__device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
+{
+    const DevParams &p = a.p;
+    const int b = it.utt;
+    int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
+    int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
+    const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
+    const int Ts = it.Ts, L = it.L;
+    const int ng = (L + 15) >> 4;
+    const uint32_t *bp = a.bp + it.bp_off;
+    int s = it.final_state;
+    const int nchunks = (Ts + 63) >> 6;
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const int t0 = c * 64;
+        const int t1 = min(Ts, t0 + 64);
+        const int t = t0 + lane;
+        const bool mine = t < t1;
+        const bool can_move = mine && t > 0;
+        int my_state = 0;
+        int t_hi = t1 - 1;
+        int g = s >> 4;
+        uint32_t wd = mine ? bp[(int64_t)t * ng + g] : 0u;
+        while (t_hi >= t0) {
+            const uint32_t code = (wd >> (2 * (s & 15))) & 3u;
+            const uint32_t k = (can_move && t <= t_hi) ? (max(code, 1u) - 1u) : 0u;
+            const unsigned long long mv = __ballot(k != 0);
+            if (mv == 0) {
+                if (t <= t_hi) my_state = s;
+                break;
+            }
+            const int jl = 63 - __builtin_clzll(mv);
+            if (t <= t_hi && lane >= jl) my_state = s;
+            s -= (int)__builtin_amdgcn_readlane((int)k, jl);
+            if (s < 0) s += L; // python negative-index wrap (:692)
+            t_hi = t0 + jl - 1;
+            if ((s >> 4) != g) { g = s >> 4; wd = mine ? bp[(int64_t)t * ng + g] : 0u; }
+        }
+        if (mine) {
+            const int o = t - it.pad_left;
+            if (o >= 0 && o < it.nout) {
+                int ph = p.blank, id = -1;
+                if (my_state >= 1) {
+                    const int q = (my_state - 1) / it.stride;
+                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
+                }
+                oph[it.out0 + o] = ph;
+                oid[it.out0 + o] = id;
+            }
+        }
+    }
+    (void)stok;
+}
+
 __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
 {
     __shared__ uint32_t sbp[16 * 64]; // one chunk: <= 1024 dwords
@@ -217,7 +273,8 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
             case 6: walk_item<6, false>(a, it, sbp, stok, lane); break;
             case 8: walk_item<8, false>(a, it, sbp, stok, lane); break;
             case 12: walk_item<12, false>(a, it, sbp, stok, lane); break;
-            default: walk_item<16, false>(a, it, sbp, stok, lane); break;
+            case 16: walk_item<16, false>(a, it, sbp, stok, lane); break;
+            default: walk_item_big(a, it, stok, lane); break;
             }
         }
     }

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
             a.cand[atomicAdd(&a.counters[1], 1)] = b;
         }
     }
-    if (it.kind == ITEM_DP && r_class_for_L(it.L) == 0) {
-        status = BFA_ITEM_TOO_LARGE; // TODO(big-L workgroup kernel)
+    if (it.kind == ITEM_DP && it.L > BIG_MAX_L) { // beyond the workgroup-wide kernel as well
+        status = BFA_ITEM_TOO_LARGE;
         it.kind = ITEM_FILL_BLANK;
     }
     a.items[b] = it;
@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256) void k_log_softmax(const float *in, int64_t ld
 extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_big_nk2(const bfa::AlignArgs *args, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_big_nk5(const bfa::AlignArgs *args, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_big_nk8(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 
@@ -385,6 +388,12 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, stream);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, stream);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, stream);
+    if (Lmax > 1024) { // paths of more than 1024 states can occur: the workgroup-wide kernel takes them
+        const int big_grid = a.B < 1024 ? a.B : 1024;
+        if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, stream);
+        else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, stream);
+        else bfa_launch_dp_big_nk8(&a, big_grid, stream);
+    }
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
     bfa_launch_backtrace(&a, dp_grid, stream);
     hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);

@@ -189,7 +189,7 @@ __global__ void k_plan_seg(AlignArgs a)
                 if ((double)(stride * nt + 1) > (double)Ts * 0.8) stride = 2;
                 const int L = stride * nt + 1;
                 if ((double)L > (double)Ts * 1.2) { ok = false; break; }
-                if (r_class_for_L(L) == 0) too_large = 1;
+                if (L > BIG_MAX_L) too_large = 1;
             }
             if (npieces == 0) ok = false; // :454-455
         }

@@ -202,6 +202,38 @@ def test_long_paths_R_classes(ora, gpu_device):
     _compare(res, exp, T_len)
 
 
+@pytest.mark.parametrize("C", [67, 17, 40])
+def test_paths_beyond_1024_states(ora, gpu_device, C):
+    """L > 1024 (more than 255 phonemes in one DP): the workgroup-wide K1 (k_dp_big) and its row-major backtrace.
+    Mixed with short utterances in the same batch; default flags, truly_forced off, and the simple mode."""
+    rng = np.random.default_rng(31 + C)
+    blank = C - 1
+    lps, toks = [], []
+    for S, T in ((256, 1025), (300, 1300), (511, 2100), (600, 2000), (30, 200), (1023, 4093), (700, 2801), (255, 1021)):
+        lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=float(rng.choice([8.0, 1.0])), repeat_rate=0.1)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+    for kw in (dict(anchors=0), dict(anchors=0, tf=False), dict(anchors=0, simple=True), dict(anchors=10)):
+        res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, **kw)
+        _compare(res, exp, T_len, check_mode=not kw.get("simple", False))
+
+
+def test_segmented_mode_with_pieces_beyond_1024_states(ora, gpu_device):
+    """Silence-anchored mode whose speech segments are themselves longer than 1024 states."""
+    rng = np.random.default_rng(77)
+    C, blank = 67, 66
+    lps, toks = [], []
+    for S, T in ((620, 2700), (700, 3000), (400, 1700)):
+        lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=9.0, sil_rate=0.004, sil_len=(14, 30))
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=10)
+    assert (exp["mode"] == 1).any(), "the case should reach the segmented mode"
+    _compare(res, exp, T_len)
+
+
 def test_confidences_parity(ora, gpu_device):
     from bournemouth_forced_aligner_amd import calculate_confidences_batch
     rng = np.random.default_rng(9)
