@@ -56,14 +56,38 @@ def synth_batch(B, T, S, C, seed, device, peak=9.0):
 
 
 def synth_ragged(B, Tlo, Thi, C, seed, device, peak=9.0):
-    """BASELINE.json configs[3] shape: T ~ U{Tlo..Thi}, S = max(1, T // 25), padded to Thi / max S."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    T_len = torch.randint(Tlo, Thi + 1, (B,), generator=g)
+    """BASELINE.json configs[3] shape: T ~ U{Tlo..Thi}, S = max(1, T // 25), padded to Thi / max S.  Every
+    utterance gets its own planted path over its own T frames and S tokens (same construction as synth_batch)."""
+    gc = torch.Generator(device="cpu")
+    gc.manual_seed(seed)
+    T_len = torch.randint(Tlo, Thi + 1, (B,), generator=gc)
     S_len = torch.clamp(T_len // 25, min=1)
     Tmax, Smax = int(T_len.max()), int(S_len.max())
-    lp, toks = synth_batch(B, Tmax, Smax, C, seed, device, peak=peak)  # planted path of the padded shape ...
-    return lp, toks, T_len.to(torch.int32), S_len.to(torch.int32)        # ... truncated per utterance by the lengths
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    blank = C - 1
+    Td, Sd = T_len.to(device), S_len.to(device)
+    toks = torch.randint(1, C - 1, (B, Smax), generator=g, device=device)
+    extra = (Td - 2 * Sd).unsqueeze(1)  # [B,1] frames not forced to a token
+    u = torch.rand((B, 2 * Smax), generator=g, device=device)
+    cuts = torch.floor(u * (extra + 1).to(u.dtype)).to(torch.int64)
+    k = torch.arange(2 * Smax, device=device).unsqueeze(0)
+    cuts = torch.where(k < 2 * Sd.unsqueeze(1), cuts, extra.expand(-1, 2 * Smax))  # unused slots get no frames
+    cuts, _ = torch.sort(cuts, dim=1)
+    zeros = torch.zeros((B, 1), dtype=cuts.dtype, device=device)
+    sizes = torch.diff(torch.cat([zeros, cuts, extra], dim=1), dim=1)  # [B, 2Smax+1] gap,tok,gap,tok,...,gap
+    tokslot = torch.arange(Smax, device=device).unsqueeze(0) < Sd.unsqueeze(1)
+    sizes[:, 1::2] += 2 * tokslot.to(sizes.dtype)
+    ends = torch.cumsum(sizes, dim=1)
+    t = torch.arange(Tmax, device=device).unsqueeze(0).expand(B, Tmax).contiguous()
+    slot = torch.searchsorted(ends, t, right=True)
+    is_tok = ((slot % 2) == 1) & (t < Td.unsqueeze(1))
+    tok_idx = torch.clamp((slot - 1) // 2, 0, Smax - 1)
+    planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
+    logits = torch.randn((B, Tmax, C), generator=g, device=device, dtype=torch.float32)
+    logits.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, Tmax, 1), peak, device=device))
+    lp = torch.log_softmax(logits, dim=-1)
+    return lp, toks.to(torch.int32), T_len.to(torch.int32), S_len.to(torch.int32)
 
 
 def main():

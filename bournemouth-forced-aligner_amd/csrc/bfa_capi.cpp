@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -13,7 +14,8 @@
 
 #include "bfa_types.hpp"
 
-extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1);
+extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1,
+                                void **aux_streams, void **aux_events, void *fork_event, int naux);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
@@ -29,6 +31,12 @@ struct bfa_context {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // recorded K1 brackets
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // reusable pairs
+    // K1 class kernels of one call run side by side on these (forked from / joined into the caller's stream)
+    static constexpr int NAUX = 6;
+    hipStream_t aux[NAUX] = {};
+    hipEvent_t aux_done[NAUX] = {};
+    hipEvent_t forked = nullptr;
+    int naux = 0;
 };
 
 namespace {
@@ -146,6 +154,19 @@ int bfa_create(bfa_handle *out, int device)
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     h->device = device;
     h->num_cu = prop.multiProcessorCount;
+    {   // auxiliary streams (best effort: without them the class kernels simply run one after the other)
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
+        const char *no_aux = getenv("BFA_NO_AUX_STREAMS"); // (measurement switch)
+        bool ok = !(no_aux && no_aux[0] == '1') && hipEventCreateWithFlags(&h->forked, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; ok && k < bfa_context::NAUX; ++k) {
+            ok = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->aux_done[k], hipEventDisableTiming) == hipSuccess;
+            if (ok) h->naux = k + 1;
+        }
+        (void)hipSetDevice(prev);
+    }
     *out = h;
     return BFA_OK;
 }
@@ -177,6 +198,11 @@ int bfa_destroy(bfa_handle h)
     if (h) {
         for (auto &pr : h->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (auto &pr : h->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (int k = 0; k < bfa_context::NAUX; ++k) {
+            if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
+            if (h->aux_done[k]) (void)hipEventDestroy(h->aux_done[k]);
+        }
+        if (h->forked) (void)hipEventDestroy(h->forked);
     }
     delete h;
     return BFA_OK;
@@ -244,7 +270,8 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
         h->events.push_back(pr);
         ev0 = (void *)pr.first; ev1 = (void *)pr.second;
     }
-    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1);
+    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done, (void *)h->forked,
+                                    h->forked ? h->naux : 0);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
             it.kind = ITEM_DP;
             it.bw = band_standard(L);
             mode = BFA_MODE_STANDARD;
-            const int rw = win_class_for(L, it.bw); // band narrow enough for the sliding-window consumer?
+            const int rw = win_class_for(L, it.bw, T); // band narrow enough (and the utterance short enough) for the window?
             if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
         }
         if (seg_candidate && status == BFA_ITEM_OK) { // k_plan_segmented decides (it may keep this fallback)
@@ -347,16 +347,20 @@ __global__ __launch_bounds__(256) void k_log_softmax(const float *in, int64_t ld
 // -------------------------------------------------------------------------------------------------
 // launchers used by bfa_capi.cpp
 // -------------------------------------------------------------------------------------------------
-extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
-extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
-extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk2(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, bfa::LaunchFan *fan);
+extern "C" void bfa_launch_dp_redo_nk2(const bfa::AlignArgs *args, unsigned class_mask, int mode, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, bfa::LaunchFan *fan);
+extern "C" void bfa_launch_dp_redo_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, hipStream_t stream);
+extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, bfa::LaunchFan *fan);
+extern "C" void bfa_launch_dp_redo_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, hipStream_t stream);
 extern "C" void bfa_launch_dp_big_nk2(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_big_nk5(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_big_nk8(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 
-extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1)
+extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
+                                void **aux_streams, void **aux_events, void *fork_event, int naux)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
@@ -374,7 +378,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (mode != 2 && (a.C == 67 || a.C == 17) && Lmax > 60) {
         wmask = 15u; // Rw = 1..4; classes no utterance can use cost one empty launch each (narrow with the hint)
         for (int rw = 4; rw >= 1; --rw) { // drop the classes above the one the longest possible path would take
-            const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20);
+            const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
             if (top > 0 && rw > top) wmask &= ~(1u << (rw - 1));
         }
         if (p.class_mask) wmask &= (p.class_mask >> 8);
@@ -385,15 +389,29 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
-    if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, stream);
-    else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, stream);
-    else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, stream);
+    // one kernel per class; with more than one class to launch they run side by side on the auxiliary streams
+    const int n_kernels = __builtin_popcount(mask & 0xf7fu) + (Lmax > 1024 ? 1 : 0);
+    LaunchFan fan;
+    fan.main_stream = stream;
+    fan.aux = (hipStream_t *)aux_streams;
+    fan.joined = (hipEvent_t *)aux_events;
+    fan.forked = (hipEvent_t)fork_event;
+    fan.naux = (n_kernels > 1 && aux_streams) ? naux : 0;
+    fan.used = 0;
     if (Lmax > 1024) { // paths of more than 1024 states can occur: the workgroup-wide kernel takes them
         const int big_grid = a.B < 1024 ? a.B : 1024;
-        if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, stream);
-        else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, stream);
-        else bfa_launch_dp_big_nk8(&a, big_grid, stream);
+        hipStream_t bs = fan.pick();
+        if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, bs);
+        else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, bs);
+        else bfa_launch_dp_big_nk8(&a, big_grid, bs);
     }
+    if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);
+    else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
+    else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, &fan);
+    fan.join();
+    if (nk <= 2) bfa_launch_dp_redo_nk2(&a, mask, mode, stream);
+    else if (nk <= 5) bfa_launch_dp_redo_nk5(&a, mask, mode, stream);
+    else bfa_launch_dp_redo_nk8(&a, mask, mode, stream);
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
     bfa_launch_backtrace(&a, dp_grid, stream);
     hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);

@@ -123,10 +123,14 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // win_frames_per_word(Rw) frames (2 bits x Rw slots per frame) and the window only moves between dwords, so it must
 // hold the band of all those frames: the 2*bw+1 in-band states + the band's advance over the dword (pace <= 1) +
 // the two below-band predecessor states + the lane granularity of the move + 1 of slack.
+// The window result is only valid while path scores stay above the sentinel -1000 (otherwise the item is redone with
+// the full layout, which costs more than never trying): scores are sums of per-frame log-probabilities, so long
+// utterances cross it even with good posteriors.  Past WIN_MAX_FRAMES frames the planner does not try the window.
+constexpr int WIN_MAX_FRAMES = 1536;
 __host__ __device__ inline int win_frames_per_word(int rw) { return rw == 1 ? 16 : (rw == 2 ? 8 : 4); }
-__host__ __device__ inline int win_class_for(int L, int bw)
+__host__ __device__ inline int win_class_for(int L, int bw, int Ts)
 {
-    if (bw <= 0) return 0;
+    if (bw <= 0 || Ts > WIN_MAX_FRAMES) return 0;
     const int rfull = r_class_for_L(L);
     if (rfull == 0) return 0;
     for (int rw = 1; rw <= 4 && rw < rfull; ++rw)
@@ -157,5 +161,35 @@ __host__ __device__ inline int64_t bp_dwords(int Ts, int L)
     if (R > 0) return quads * bp_words_for_R(R) * bp_lanes(L, R) + quads; // + room for the window layout's per-quad base
     return (int64_t)Ts * ((L + 15) / 16); // big-L kernel: 2 bits per state, row-major
 }
+
+// K1 launches one kernel per register class; the classes work on disjoint items, so on a mixed-length batch they
+// run side by side on the handle's auxiliary streams (forked from and joined back into the caller's stream).
+#ifdef __HIPCC__
+struct LaunchFan {
+    hipStream_t main_stream;
+    hipStream_t *aux;   // may be null
+    hipEvent_t *joined; // one per aux stream
+    hipEvent_t forked;
+    int naux, used;
+    hipStream_t pick()
+    {
+        if (naux <= 0) return main_stream;
+        if (used == 0) (void)hipEventRecord(forked, main_stream);
+        const int k = used % naux;
+        if (used < naux) (void)hipStreamWaitEvent(aux[k], forked, 0);
+        ++used;
+        return aux[k];
+    }
+    void join()
+    {
+        const int n = used < naux ? used : naux;
+        for (int k = 0; k < n; ++k) {
+            (void)hipEventRecord(joined[k], aux[k]);
+            (void)hipStreamWaitEvent(main_stream, joined[k], 0);
+        }
+        used = 0;
+    }
+};
+#endif
 
 } // namespace bfa

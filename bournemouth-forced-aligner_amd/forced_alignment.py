@@ -133,13 +133,15 @@ class ViterbiDecoder:
                 return i
         return None
 
+    _WIN_MAX_FRAMES = 1536  # bfa_types.hpp WIN_MAX_FRAMES
+
     @classmethod
-    def _win_class(cls, L):
-        """Sliding-window class (states per lane) the planner picks for a standard-mode DP of L states, or 0
-        (bfa_types.hpp win_class_for)."""
+    def _win_class(cls, L, T=0):
+        """Sliding-window class (states per lane) the planner picks for a standard-mode DP of L states over T
+        frames, or 0 (bfa_types.hpp win_class_for)."""
         bw = max(L // 4, 20) if L > 60 else 0
         full = cls._r_class(L)
-        if bw <= 0 or full is None:
+        if bw <= 0 or full is None or T > cls._WIN_MAX_FRAMES:
             return 0
         rfull = (2, 3, 4, 6, 8, 12, 16)[full]
         for rw in (1, 2, 3, 4):
@@ -182,7 +184,7 @@ class ViterbiDecoder:
             c = self._r_class(L)
             if c is None:
                 continue
-            rw = self._win_class(L) if (window_ok and L <= T) else 0
+            rw = self._win_class(L, T) if (window_ok and L <= T) else 0
             if rw:
                 mask |= 1 << (7 + rw)  # the rare sentinel rerun of a window item needs no hint bit
             else:

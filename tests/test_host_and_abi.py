@@ -109,7 +109,8 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False, n_classes=67) == NS | 1 << 9
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=67) == NS | 1 << 8
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=40) == NS | 0b1       # other widths: generic kernel
-    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
+    assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
+    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001       # T > 1536: full layout
     assert vd.class_mask_hint([], [], has_sil=False) == 0
 
 
