@@ -104,6 +104,29 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
             rowoff = row * W * nl;
             sh0 = 0;
         }
+        if (WIN) {
+            // lean loop: one exit, scalar bookkeeping only (window items never wrap below state 0: their path scores
+            // are above the sentinel)
+            const int n = t1 - t0;
+            unsigned long long todo = (n == 64) ? ~0ull : ((1ull << n) - 1ull); // frames the walk has not passed
+            if (t0 == 0) todo &= ~1ull;                                          // frame 0 has no predecessor
+            int hi = n - 1;                                                      // lanes (.., hi] still unlabelled
+            for (;;) {
+                // a frame at which s lies outside the window is below the next move: its code is not used
+                const int d = s - wbase;
+                const int dc = min(max(d, 0), 64 * R - 1);
+                const int xl = dc / R, xr = dc - xl * R;
+                const uint32_t wd = sbp[rowoff + xl];
+                const uint32_t code = ((unsigned)d < (unsigned)(64 * R)) ? ((wd >> (sh0 - 2 * xr)) & 3u) : 0u;
+                const unsigned long long mv = __ballot(code >= 2u) & todo; // (A<<1)|B : k = A ? (B ? 2 : 1) : 0
+                const int jl = (mv == 0ull) ? 0 : 63 - __builtin_clzll(mv); // latest frame at which the path moves
+                if (lane >= jl && lane <= hi) my_state = s;
+                if (mv == 0ull) break; // the path stays in s down to the chunk start
+                s -= (int)__builtin_amdgcn_readlane((int)code, jl) - 1;
+                hi = jl - 1;
+                todo &= (1ull << jl) - 1ull;
+            }
+        } else
         while (t_hi >= t0) {
             // backpointer code of this lane's frame for the CURRENT state (state[t-1] = s - k at frame t)
             uint32_t code = 0;
