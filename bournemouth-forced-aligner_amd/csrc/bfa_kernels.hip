@@ -170,17 +170,16 @@ __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
                 const int t = base + lane;
                 const bool in = t < Tr;
                 const int cph = vph[u], cix = vix[u];
-                int pph = __shfl_up(cph, 1), pix = __shfl_up(cix, 1);
+                int pph = __builtin_amdgcn_update_dpp(0, cph, DPP_WAVE_SHR1, 0xf, 0xf, true); // lane l <- lane l-1
+                int pix = __builtin_amdgcn_update_dpp(0, cix, DPP_WAVE_SHR1, 0xf, 0xf, true);
                 if (lane == 0) { pph = run_ph; pix = run_ix; }
                 const bool is_start = in && (t == 0 || cph != pph || cix != pix); // :798-801
                 const unsigned long long m = __ballot(is_start);
                 // a start at t>0 closes the run that began at the previous start (shuffles stay convergent)
                 const unsigned long long below = m & ((1ull << lane) - 1ull);
                 const int src = below ? (63 - __builtin_clzll(below)) : 0;
-                const int sph = __shfl(cph, src), six = __shfl(cix, src);
                 const int ps = below ? (base + src) : run_start;
-                const int pp = below ? sph : run_ph;
-                const int pi = below ? six : run_ix;
+                const int pp = pph, pi = pix; // every frame of the closing run carries its (phoneme, index)
                 const bool closes = is_start && t > 0;
                 bool emit = false;
                 if (closes) {
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
                 }
                 count += __builtin_popcountll(em);
                 const int last = m ? (63 - __builtin_clzll(m)) : 0;
-                const int lph = __shfl(cph, last), lix = __shfl(cix, last);
+                const int lph = __builtin_amdgcn_readlane(cph, last), lix = __builtin_amdgcn_readlane(cix, last);
                 if (m) { run_start = base + last; run_ph = lph; run_ix = lix; }
             }
         }
