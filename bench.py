@@ -198,7 +198,7 @@ def main():
     achieved = frames_per_step * bytes_per_frame / (k1_ms * 1e-3) / 1e9 if k1_ms == k1_ms else None
 
     cpu = None
-    if rank == 0 and not args.no_cpu and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:  # timed at N=1 only
         from oracle import oracle as ora
         prm = ora.make_params(blank, sil)
         per = min(args.cpu_sample, B)

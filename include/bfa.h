@@ -21,7 +21,9 @@
  *   - the caller owns every buffer, including outputs and the workspace (size it with
  *     bfa_workspace_bytes); the library allocates nothing per call and never frees caller memory;
  *   - calls are stream-ordered and return without synchronising; buffers must stay alive until
- *     the stream has been synchronised;
+ *     the stream has been synchronised.  Inside a call the alignment kernels of different length
+ *     classes may run side by side on streams owned by the handle; they are forked from and joined
+ *     back into `stream` with events, so the ordering the caller sees is that of `stream` alone;
  *   - return value: BFA_OK or a negative bfa_status for call-level failures (bad argument,
  *     launch failure).  Per-utterance outcomes go to out_status[B] (see BFA_ITEM_*);
  *   - one handle per GPU per host thread; no hidden global state.
