@@ -266,11 +266,16 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
             continue;
         }
         if (it.kind == ITEM_FILL_SIL) { // forced_alignment.py:382-397
-            const double fps = (it.nt > 0) ? (double)it.nout / (double)it.nt : 0.0;
+            // frames per SIL token of the WHOLE silence segment (it.Ts frames); only the first it.nout of them are
+            // written when the concatenation is cut off at T (:465-467)
+            const double fps = (it.nt > 0) ? (double)it.Ts / (double)it.nt : 0.0;
             for (int t = lane; t < it.nout; t += 64) {
                 int id = -1;
-                if (it.nt > 0) { // the k with int(k*fps) <= t < int((k+1)*fps); the ranges are disjoint
-                    const int k = (int)((double)t / fps);
+                if (it.nt > 0) {
+                    // the k with int(k*fps) <= t < int((k+1)*fps), i.e. k*fps < t+1 <= (k+1)*fps: k = ceil((t+1)/fps) - 1
+                    // (ranges are disjoint; with more SIL tokens than frames most of them are empty); the candidates
+                    // around that estimate are tested with the reference's own double products
+                    const int k = (int)__builtin_ceil((double)(t + 1) / fps) - 1;
                     for (int kk = max(0, k - 1); kk <= min(it.nt - 1, k + 1); ++kk) {
                         const int f0 = (int)((double)kk * fps), f1 = (int)((double)(kk + 1) * fps);
                         if (t >= f0 && t < f1) id = it.tok0 + kk;
@@ -281,6 +286,11 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
             continue;
         }
         if (it.kind != ITEM_DP) continue;
+        if (it.final_state < 0) { // no K1 kernel took this item: its class was missing from the caller's class hint
+            for (int t = lane; t < it.nout; t += 64) { oph[it.out0 + t] = p.blank; oid[it.out0 + t] = -1; }
+            if (lane == 0 && a.status[b] == BFA_ITEM_OK) a.status[b] = BFA_ITEM_BAD_HINT;
+            continue;
+        }
         if (it.win > 0) {
             switch (it.win) {
             case 1: walk_item<1, true>(a, it, sbp, stok, lane); break;

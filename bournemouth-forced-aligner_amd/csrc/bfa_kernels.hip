@@ -78,13 +78,13 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 
     Item it;
     it.kind = ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = T; it.tok0 = 0; it.nt = S; it.stride = 0; it.L = 0;
-    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = 0; it.anch_off = -1; it.win = 0; it.pad_ = 0;
+    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.pad_ = 0;
     it.bp_off = (int64_t)b * a.bp_per_utt;
     int mode = BFA_MODE_EMPTY;
 
     if (status != BFA_ITEM_OK) {
         it.kind = ITEM_FILL_BLANK;
-    } else if (S == 0) { // :894-897 (and :112-118)
+    } else if (S == 0 && !p.simple) { // :894-897 (and :112-118); decode_alignments_simple has no such shortcut (:951-985)
         it.kind = ITEM_FILL_BLANK;
         mode = BFA_MODE_EMPTY;
     } else if (p.simple) { // forced_alignment.py:963-976, lengths are 0-dim int64 tensors -> float32 compares
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
         int32_t *ix = a.frame_idx + (int64_t)b * a.Tmax;
         const int T = a.uT[b];
         const int st = a.status[b];
-        const bool none = (st != BFA_ITEM_OK) || a.uS[b] == 0;
+        const bool none = (st != BFA_ITEM_OK) || (a.uS[b] == 0 && !p.simple);
         const int Tr = none ? 0 : T; // frames that take part in the run-length encoding
         for (int t = Tr + lane; t < a.Tmax; t += 64) { ph[t] = p.blank; ix[t] = -1; }
         bfa_segment *out = a.segs + (int64_t)b * a.seg_cap;

@@ -76,7 +76,8 @@ class AlignmentResult:
             if st[b] == _lib.ITEM_SEG_OVERFLOW:
                 raise RuntimeError(f"item {b}: more aligned runs than seg_cap")
             if st[b] == _lib.ITEM_BAD_HINT:
-                raise RuntimeError(f"item {b}: class_mask hint said no target contains the silence id, but this one does")
+                raise RuntimeError(f"item {b}: the class_mask hint excludes what this utterance needs (a K1 class bit is "
+                                   f"missing, or no-silence was promised although the target contains the silence id)")
 
     def to_lists(self):
         """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871)."""
@@ -182,14 +183,15 @@ class ViterbiDecoder:
                         stride = s2
             L = stride * S + 1
             c = self._r_class(L)
+            ctop = self._r_class(4 * S + 1)  # widest class a speech segment of this utterance can need
+            top = max(top, 6 if ctop is None else ctop)
             if c is None:
-                continue
+                continue  # more than 1024 states: the workgroup-wide kernel, launched from the shapes alone
             rw = self._win_class(L, T) if (window_ok and L <= T) else 0
             if rw:
                 mask |= 1 << (7 + rw)  # the rare sentinel rerun of a window item needs no hint bit
             else:
                 mask |= 1 << c
-            top = max(top, self._r_class(4 * S + 1) or 6)
         if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and top >= 0:
             mask |= (1 << (top + 1)) - 1
         if not has_sil and mask:

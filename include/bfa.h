@@ -58,7 +58,8 @@ typedef enum {
 #define BFA_ITEM_BAD_TOKEN 2   /* token id outside [0,C) : reference raises IndexError */
 #define BFA_ITEM_TOO_LARGE 3   /* CTC path longer than this build supports (8192 states = 2047 phonemes in one DP) */
 #define BFA_ITEM_SEG_OVERFLOW 4 /* more runs than seg_cap: frame outputs are valid, segments truncated */
-#define BFA_ITEM_BAD_HINT 5     /* reserved[0] said BFA_HINT_NO_SILENCE_TARGETS but this target contains silence_id */
+#define BFA_ITEM_BAD_HINT 5     /* the reserved[0] hint excluded what this utterance needs: BFA_HINT_NO_SILENCE_TARGETS
+                                   although the target contains silence_id, or a K1 class bit that is missing */
 
 #define BFA_HINT_NO_SILENCE_TARGETS (1 << 16)
 

@@ -156,6 +156,11 @@ def test_no_silence_hint_is_checked(gpu_device):
     assert st[0] == _lib.ITEM_OK and st[1] == _lib.ITEM_BAD_HINT
     with pytest.raises(RuntimeError):
         res.raise_for_status()
+    # a hint without the class an utterance needs is reported as well (here: only R = 16 for a path of 49 states)
+    res = au.viterbi_decoder.align_batch(torch.from_numpy(lpb[:1]).to(gpu_device), torch.from_numpy(tkb[:1]), T_len[:1],
+                                         S_len[:1], class_mask=(1 << 6) | _lib.HINT_NO_SILENCE_TARGETS)
+    torch.cuda.synchronize()
+    assert res.status.cpu().numpy()[0] == _lib.ITEM_BAD_HINT
 
 
 def test_ignore_noise_false_and_given_emissions(ora, gpu_device):
@@ -232,6 +237,39 @@ def test_segmented_mode_with_pieces_beyond_1024_states(ora, gpu_device):
     res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=10)
     assert (exp["mode"] == 1).any(), "the case should reach the segmented mode"
     _compare(res, exp, T_len)
+
+
+def test_soak_regressions(ora, gpu_device):
+    """Cases the randomized soak (tools/soak.py) found: a silence segment whose SIL indices are spread over the whole
+    segment although the concatenation is cut off at T; one with more SIL tokens than frames (empty index ranges)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_regressions.npz"))
+    for name in ("sil_cut_at_T", "more_sil_tokens_than_frames"):
+        lp1, tk1 = z[name + "_lp"], z[name + "_tk"]
+        C, anchors, tf, ign, simple, boost, enf = (int(v) for v in z[name + "_cfg"])
+        lp, tk, T_len, S_len = cases.pad_batch([lp1], [tk1], C, C - 1)
+        res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=anchors, ign=bool(ign), tf=bool(tf),
+                             boost=bool(boost), enf=bool(enf), simple=bool(simple))
+        assert exp["mode"][0] == 1
+        _compare(res, exp, T_len)
+
+
+def test_simple_mode_empty_target(ora, gpu_device):
+    """decode_alignments_simple has no empty-target shortcut (forced_alignment.py:951-985): S = 0 runs the DP over the
+    single blank state, and with ignore_noise=False a long blank run is reported."""
+    rng = np.random.default_rng(3)
+    C, blank = 67, 66
+    lps, toks = [], []
+    for T, S in ((17, 0), (64, 0), (5, 0), (40, 3)):
+        lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=5.0)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+    for ign in (False, True):
+        res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=0, ign=ign, simple=True)
+        _compare(res, exp, T_len, check_mode=False)
+        if not ign:
+            assert exp["seg_count"][0] == 1 and exp["seg_count"][1] == 1 and exp["seg_count"][2] == 0
 
 
 def test_confidences_parity(ora, gpu_device):

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""tools/soak.py [n_batches] [seed] -- randomized differential soak of the HIP path against the CPU oracle
+(run on the GPU box).  Every batch draws its own head width, flags, length ranges and posterior sharpness;
+integer outputs must be identical.  Not part of pytest (minutes); prints one line per mismatch and a summary."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from oracle import oracle as ora  # noqa: E402
+from bournemouth_forced_aligner_amd import AlignmentUtils  # noqa: E402
+
+
+def main():
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    bad = 0
+    items = 0
+    t0 = time.time()
+    for it in range(nb):
+        C = int(rng.choice([67, 67, 67, 17, 17, 40]))
+        blank = C - 1
+        anchors = int(rng.choice([0, 0, 10, 3]))
+        tf = bool(rng.integers(0, 2))
+        ign = bool(rng.integers(0, 4) != 0)
+        simple = bool(rng.integers(0, 8) == 0)
+        boost = bool(rng.integers(0, 6) != 0)
+        enf = bool(rng.integers(0, 6) != 0)
+        regime = int(rng.integers(0, 5))
+        n = int(rng.integers(4, 40))
+        lps, toks = [], []
+        for _ in range(n):
+            if regime == 0:      # headline-like: window classes
+                S = int(rng.integers(15, 125)); T = int(rng.integers(4 * S + 1, min(1600, 12 * S) + 1))
+            elif regime == 1:    # tight: T close to L, strides 1..4
+                S = int(rng.integers(1, 200)); T = int(rng.integers(max(1, S - 2), 5 * S + 8))
+            elif regime == 2:    # long
+                S = int(rng.integers(60, 420)); T = int(rng.integers(4 * S + 1, 4 * S + 900))
+            elif regime == 3:    # tiny
+                S = int(rng.integers(0, 12)); T = int(rng.integers(1, 90))
+            else:                # mixed
+                T = int(rng.integers(8, 1200)); S = int(rng.integers(1, max(2, T // 3)))
+            peak = float(rng.choice([9.0, 6.0, 3.0, 1.0, 0.2]))
+            sil_rate = float(rng.choice([0.0, 0.0, 0.08, 0.2])) if anchors > 0 else 0.0
+            lp, tk, _ = cases.planted_case(rng, max(T, 1), S, C=C, blank=blank, peak=peak, sigma=float(rng.choice([1.0, 2.0])),
+                                           sil_rate=sil_rate, repeat_rate=float(rng.choice([0.0, 0.15])))
+            lps.append(lp); toks.append(tk)
+        lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+        au = AlignmentUtils(blank, 0, silence_anchors=anchors, ignore_noise=ign, truly_forced=tf)
+        hint = 0
+        if rng.integers(0, 2):
+            has_sil = bool((tk == 0).any())
+            hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=has_sil, anchor_pauses=anchors > 0,
+                                                      simple=simple, n_classes=C, boost_targets=boost, enforce_minimum=enf)
+        res = au.viterbi_decoder.align_batch(torch.from_numpy(lp).to(dev), torch.from_numpy(tk), T_len, S_len,
+                                             boost_targets=boost, enforce_minimum=enf, anchor_pauses=anchors > 0,
+                                             simple=simple, seg_cap=lp.shape[1] + 1, class_mask=hint)
+        torch.cuda.synchronize()
+        prm = ora.make_params(blank, 0, anchors, ign, tf, boost, enf)
+        exp = ora.decode_alignments(lp, tk, T_len, S_len, prm, simple=simple)
+        st = res.status.cpu().numpy()
+        fph = res.frame_phonemes.cpu().numpy(); fidx = res.frame_phonemes_idx.cpu().numpy()
+        cnt = res.seg_count.cpu().numpy(); segs = res.segs.cpu().numpy()
+        for b in range(n):
+            items += 1
+            ok = st[b] == exp["status"][b]
+            if ok and st[b] == 0:
+                T = int(T_len[b])
+                ok = (fph[b, :T] == exp["frame_ph"][b, :T]).all() and (fidx[b, :T] == exp["frame_idx"][b, :T]).all() \
+                    and cnt[b] == exp["seg_count"][b] and (segs[b, :cnt[b]] == exp["seg"][b, :cnt[b]]).all()
+            if not ok:
+                bad += 1
+                dump = os.path.join(ROOT, "gpurun_out", f"soak_s{seed}_b{it}_i{b}.npz")
+                os.makedirs(os.path.dirname(dump), exist_ok=True)
+                np.savez_compressed(dump, lp=lp[b, :int(T_len[b])], tk=tk[b, :int(S_len[b])], C=C, anchors=anchors, tf=tf,
+                                    ign=ign, simple=simple, boost=boost, enf=enf, got_ph=fph[b], got_idx=fidx[b],
+                                    exp_ph=exp["frame_ph"][b], exp_idx=exp["frame_idx"][b], mode=exp["mode"][b])
+                print(f"MISMATCH batch {it} item {b}: C={C} T={int(T_len[b])} S={int(S_len[b])} anchors={anchors} tf={tf} ign={ign} "
+                      f"simple={simple} boost={boost} enf={enf} hint={hint:#x} status={st[b]}/{exp['status'][b]}", flush=True)
+    print(f"soak: {items} utterances in {nb} batches, {bad} mismatching, {time.time() - t0:.0f} s (seed {seed})")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
