@@ -23,6 +23,7 @@ def main():
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda", 0)
     bad = 0
+    bad2 = 0
     items = 0
     t0 = time.time()
     for it in range(nb):
@@ -85,8 +86,35 @@ def main():
                                     exp_ph=exp["frame_ph"][b], exp_idx=exp["frame_idx"][b], mode=exp["mode"][b])
                 print(f"MISMATCH batch {it} item {b}: C={C} T={int(T_len[b])} S={int(S_len[b])} anchors={anchors} tf={tf} ign={ign} "
                       f"simple={simple} boost={boost} enf={enf} hint={hint:#x} status={st[b]}/{exp['status'][b]}", flush=True)
-    print(f"soak: {items} utterances in {nb} batches, {bad} mismatching, {time.time() - t0:.0f} s (seed {seed})")
-    return 1 if bad else 0
+        # ---- post-DP stages on the GPU's own tuples: confidences (utils.py:70-113), then ensure_target_coverage
+        # (default) + extend_soft_boundaries (core.py:925-931)
+        if (st == 0).all() and n > 0:
+            from bournemouth_forced_aligner_amd import calculate_confidences_batch
+            from bournemouth_forced_aligner_amd.utils import postprocess_batch
+            lpd = torch.from_numpy(lp).to(dev)
+            conf, _cst = calculate_confidences_batch(lpd, res.segs, res.seg_count)
+            conf = conf.cpu().numpy()
+            soft = int(rng.choice([3, 2, 5]))
+            segs2 = res.segs.clone()
+            cnt2 = res.seg_count.clone()
+            postprocess_batch(lpd, torch.from_numpy(np.asarray(S_len, np.int32)), segs2, cnt2, extend=True, boundary_softness=soft)
+            torch.cuda.synchronize()
+            segs2 = segs2.cpu().numpy(); cnt2 = cnt2.cpu().numpy()
+            for b in range(n):
+                tup = [tuple(int(v) for v in r) for r in segs[b, :cnt[b]]]
+                rc, c, _s, _e = ora.confidences(lp[b], tup)
+                okc = rc == 0 and (conf[b, :cnt[b]].view(np.int32) == c.view(np.int32)).all()
+                cov = ora.ensure_target_coverage_default(tup, int(S_len[b]))
+                ext = ora.extend_soft_boundaries(lp[b], cov, soft) if cov else []
+                got = [tuple(int(v) for v in r) for r in segs2[b, :cnt2[b]]]
+                okp = got == ext
+                if not (okc and okp):
+                    bad2 += 1
+                    print(f"POST-DP MISMATCH batch {it} item {b}: C={C} T={int(T_len[b])} S={int(S_len[b])} conf_ok={okc} post_ok={okp} "
+                          f"softness={soft}", flush=True)
+    print(f"soak: {items} utterances in {nb} batches, {bad} mismatching, {bad2} post-DP mismatches, "
+          f"{time.time() - t0:.0f} s (seed {seed})")
+    return 1 if (bad or bad2) else 0
 
 
 if __name__ == "__main__":
