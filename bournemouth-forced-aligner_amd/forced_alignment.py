@@ -31,6 +31,23 @@ def _as_i32(x, device, n=None):
     return x.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
 
 
+def _host_array(x):
+    """x as a numpy array if it lives on the host (list / ndarray / CPU tensor), else None (no device sync)."""
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.numpy() if x.device.type == "cpu" else None
+    try:
+        return np.asarray(x)
+    except Exception:
+        return None
+
+
+def _host_ints(x):
+    a = _host_array(x)
+    return None if a is None else a.astype(np.int64).reshape(-1)
+
+
 class _Workspace:
     """Caller-owned scratch for bfa_align_batch, cached per shape."""
 
@@ -163,37 +180,43 @@ class ViterbiDecoder:
         shorter DPs, and every full class up to the largest is kept; otherwise bit 16 tells the library to
         skip the silence planning, and a target that does contain it is reported as ITEM_BAD_HINT).  Without a hint the library launches
         every class the tensor shapes allow."""
-        mask, top = 0, -1
+        T = np.asarray(list(T_lens) if not isinstance(T_lens, np.ndarray) else T_lens, dtype=np.int64).reshape(-1)
+        S = np.asarray(list(S_lens) if not isinstance(S_lens, np.ndarray) else S_lens, dtype=np.int64).reshape(-1)
+        if T.size == 0:
+            return 0
         window_ok = (n_classes in (67, 17)) and boost_targets and enforce_minimum and not simple
-        for T, S in zip(T_lens, S_lens):
-            T, S = int(T), int(S)
-            if S <= 0:
-                continue
-            if simple:
-                f32 = np.float32
-                stride = 4
-                if f32(stride * S + 1) > f32(T) * f32(0.9):
-                    stride = 3
-                if f32(stride * S + 1) > f32(T) * f32(0.8):
-                    stride = 2
-            else:
-                stride = 4
-                for s2 in (3, 2, 1):
-                    if stride * S + 1 > T:
-                        stride = s2
+        classes = np.array((2, 3, 4, 6, 8, 12, 16))
+        if simple:  # forced_alignment.py:963-968 (float32 compares); S = 0 still runs a DP over the single blank state
+            f32 = np.float32
+            stride = np.full(T.shape, 4, np.int64)
+            stride[(4 * S + 1).astype(f32) > T.astype(f32) * f32(0.9)] = 3
+            stride[(stride * S + 1).astype(f32) > T.astype(f32) * f32(0.8)] = 2
             L = stride * S + 1
-            c = self._r_class(L)
-            ctop = self._r_class(4 * S + 1)  # widest class a speech segment of this utterance can need
-            top = max(top, 6 if ctop is None else ctop)
-            if c is None:
-                continue  # more than 1024 states: the workgroup-wide kernel, launched from the shapes alone
-            rw = self._win_class(L, T) if (window_ok and L <= T) else 0
-            if rw:
-                mask |= 1 << (7 + rw)  # the rare sentinel rerun of a window item needs no hint bit
-            else:
-                mask |= 1 << c
-        if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and top >= 0:
-            mask |= (1 << (top + 1)) - 1
+            is_dp = T >= 1
+        else:       # forced_alignment.py:153-176
+            stride = np.full(T.shape, 4, np.int64)
+            for s2 in (3, 2, 1):
+                stride[stride * S + 1 > T] = s2
+            L = stride * S + 1
+            is_dp = (S > 0) & (L <= T)
+        ci = np.searchsorted(classes, (L + 63) // 64)            # index of the full-layout class, 7 = beyond 1024 states
+        mask = 0
+        rw = np.zeros(T.shape, np.int64)
+        if window_ok:                                            # bfa_types.hpp win_class_for
+            bw = np.where(L > 60, np.maximum(L // 4, 20), 0)
+            rfull = classes[np.minimum(ci, 6)]
+            for r in (4, 3, 2, 1):
+                fpw = {1: 16, 2: 8}.get(r, 4)
+                fits = (2 * bw + 1 + fpw + 2 + r + 1 <= 64 * r) & (r < rfull)
+                rw[fits] = r
+            rw[(bw <= 0) | (T > self._WIN_MAX_FRAMES) | (ci > 6) | ~is_dp] = 0
+        for r in np.unique(rw[rw > 0]):
+            mask |= 1 << (7 + int(r))                            # (the rare sentinel rerun needs no hint bit)
+        for c in np.unique(ci[is_dp & (rw == 0) & (ci <= 6)]):
+            mask |= 1 << int(c)
+        if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and (S > 0).any():
+            top = int(np.minimum(np.searchsorted(classes, (4 * S[S > 0] + 1 + 63) // 64), 6).max())
+            mask |= (1 << (top + 1)) - 1                         # speech segments can be any shorter class
         if not has_sil and mask:
             mask |= _lib.HINT_NO_SILENCE_TARGETS  # the silence-anchored planning kernels are not launched
         return mask
@@ -215,6 +238,19 @@ class ViterbiDecoder:
         Smax = max(1, toks.shape[1])
         if toks.shape[1] == 0:
             toks = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+        if class_mask is None:
+            class_mask = 0
+        elif class_mask == 0:
+            # lengths (and tokens) that are still on the host cost nothing to look at: derive the class hint, so
+            # that only the K1 classes of this batch are launched (class_mask=None keeps the library's own choice)
+            Th, Sh = _host_ints(pred_lens), _host_ints(true_seqs_lens)
+            if Th is not None and Sh is not None and len(Th) == B and len(Sh) == B:
+                tk_host = _host_array(true_seqs)
+                sil = self.silence_id if self.silence_id is not None else -1
+                has_sil = True if tk_host is None else bool((tk_host == sil).any())
+                class_mask = self.class_mask_hint(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil,
+                                                  anchor_pauses=anchor_pauses, simple=simple, n_classes=C,
+                                                  boost_targets=boost_targets, enforce_minimum=enforce_minimum)
         S_len = _as_i32(true_seqs_lens, dev)
         T_len = _as_i32(pred_lens, dev)
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)

@@ -56,7 +56,7 @@ def main():
             lps.append(lp); toks.append(tk)
         lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
         au = AlignmentUtils(blank, 0, silence_anchors=anchors, ignore_noise=ign, truly_forced=tf)
-        hint = 0
+        hint = None if rng.integers(0, 2) else 0   # None: no hint at all; 0: derived by align_batch from the host lengths
         if rng.integers(0, 2):
             has_sil = bool((tk == 0).any())
             hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=has_sil, anchor_pauses=anchors > 0,
@@ -85,7 +85,7 @@ def main():
                                     ign=ign, simple=simple, boost=boost, enf=enf, got_ph=fph[b], got_idx=fidx[b],
                                     exp_ph=exp["frame_ph"][b], exp_idx=exp["frame_idx"][b], mode=exp["mode"][b])
                 print(f"MISMATCH batch {it} item {b}: C={C} T={int(T_len[b])} S={int(S_len[b])} anchors={anchors} tf={tf} ign={ign} "
-                      f"simple={simple} boost={boost} enf={enf} hint={hint:#x} status={st[b]}/{exp['status'][b]}", flush=True)
+                      f"simple={simple} boost={boost} enf={enf} hint={hint} status={st[b]}/{exp['status'][b]}", flush=True)
         # ---- post-DP stages on the GPU's own tuples: confidences (utils.py:70-113), then ensure_target_coverage
         # (default) + extend_soft_boundaries (core.py:925-931)
         if (st == 0).all() and n > 0:
