@@ -61,7 +61,16 @@ def main():
             has_sil = bool((tk == 0).any())
             hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=has_sil, anchor_pauses=anchors > 0,
                                                       simple=simple, n_classes=C, boost_targets=boost, enforce_minimum=enf)
-        res = au.viterbi_decoder.align_batch(torch.from_numpy(lp).to(dev), torch.from_numpy(tk), T_len, S_len,
+        # the boundary takes any row / batch stride (last dimension contiguous): pad rows and shift the base now and then
+        lpd_in = torch.from_numpy(lp).to(dev)
+        padc = int(rng.choice([0, 0, 1, 3, 5]))
+        if padc or rng.integers(0, 3) == 0:
+            shift = int(rng.integers(0, 4))
+            big = torch.full((lp.shape[0], lp.shape[1] + 1, C + padc + shift), -7.0, dtype=torch.float32, device=dev)
+            big[:, :lp.shape[1], shift:shift + C] = lpd_in
+            lpd_in = big[:, :lp.shape[1], shift:shift + C]
+            assert lpd_in.stride(2) == 1
+        res = au.viterbi_decoder.align_batch(lpd_in, torch.from_numpy(tk), T_len, S_len,
                                              boost_targets=boost, enforce_minimum=enf, anchor_pauses=anchors > 0,
                                              simple=simple, seg_cap=lp.shape[1] + 1, class_mask=hint)
         torch.cuda.synchronize()
@@ -91,7 +100,7 @@ def main():
         if (st == 0).all() and n > 0:
             from bournemouth_forced_aligner_amd import calculate_confidences_batch
             from bournemouth_forced_aligner_amd.utils import postprocess_batch
-            lpd = torch.from_numpy(lp).to(dev)
+            lpd = lpd_in
             conf, _cst = calculate_confidences_batch(lpd, res.segs, res.seg_count)
             conf = conf.cpu().numpy()
             soft = int(rng.choice([3, 2, 5]))
