@@ -151,7 +151,10 @@ def main():
     if not os.environ.get("BFA_HIP_LIBRARY"):  # (kernel-time experiments with a stubbed role produce garbage)
         assert (st == 0).all(), f"alignment failed on the bench workload: {np.unique(st)}"
 
-    lib.bfa_profile_enable(h, 1)
+    # K1 of every step is bracketed with HIP events on the launch stream (measured: no effect on the step time;
+    # BFA_BENCH_K1_EVERY=n samples every n-th step instead)
+    k1_every = int(os.environ.get("BFA_BENCH_K1_EVERY", "1"))
+    lib.bfa_profile_enable(h, k1_every)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -268,7 +271,7 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "bytes per K1 launch (rocprofv3 PMC, profiles/r01_k1_traffic.json)",
                          "algorithmic_bytes_per_launch": frames_per_step * bytes_per_frame,
-                         "kernel": "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer; HIP events also span the k_dp4_redo launch)", "kernel_ms": k1_ms,
+                         "kernel": "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer; HIP events also span the k_dp4_redo launch)", "kernel_ms": k1_ms, "kernel_ms_samples": int(nk1),
                          "algorithmic_bytes_per_frame": bytes_per_frame},
             "cpu_baseline": cpu,
             "confidence_pass_ms": conf_ms,

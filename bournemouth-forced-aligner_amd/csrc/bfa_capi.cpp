@@ -28,7 +28,8 @@ struct bfa_context {
     int device;
     int num_cu;
     std::string err;
-    bool profile = false;
+    int profile = 0;       // 0 off, n >= 1: bracket K1 of every n-th bfa_align_batch call
+    int profile_tick = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // recorded K1 brackets
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // reusable pairs
     // K1 class kernels of one call run side by side on these (forked from / joined into the caller's stream)
@@ -174,7 +175,8 @@ int bfa_create(bfa_handle *out, int device)
 int bfa_profile_enable(bfa_handle h, int on)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
-    h->profile = on != 0;
+    h->profile = on > 0 ? on : 0;
+    h->profile_tick = 0;
     return BFA_OK;
 }
 
@@ -263,7 +265,7 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     // one wavefront per work item; surplus items are taken by the blocks' stride loops
     int grid = l.item_cap < 16384 ? l.item_cap : 16384;
     void *ev0 = nullptr, *ev1 = nullptr;
-    if (h->profile) {
+    if (h->profile > 0 && (h->profile_tick++ % h->profile) == 0) {
         std::pair<hipEvent_t, hipEvent_t> pr;
         if (!h->pool.empty()) { pr = h->pool.back(); h->pool.pop_back(); }
         else { (void)hipEventCreate(&pr.first); (void)hipEventCreate(&pr.second); }

@@ -160,8 +160,9 @@ int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t st
                     int boundary_softness, void *stream);
 
 /*
- * Measurement hooks (bench.py): when enabled, every bfa_align_batch call brackets its K1 launches
- * (the banded-Viterbi forward kernel) with a pair of HIP events on the caller's stream.
+ * Measurement hooks (bench.py): with on = n >= 1, every n-th bfa_align_batch call brackets its K1 launches
+ * (the banded-Viterbi forward kernel) with a pair of HIP events on the caller's stream (n > 1 samples);
+ * on = 0 switches it off.
  * bfa_profile_collect synchronises on the recorded events, writes up to `cap` K1 durations in
  * milliseconds (oldest first), clears the list and returns how many were written.
  */
