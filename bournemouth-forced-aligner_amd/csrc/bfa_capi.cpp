@@ -57,7 +57,11 @@ struct Carve {
     }
 };
 
-bool segmented_possible(const bfa_params *p) { return !p->simple && p->silence_anchors > 0 && p->silence_id >= 0; }
+bool segmented_possible(const bfa_params *p)
+{
+    return !p->simple && p->silence_anchors > 0 && p->silence_id >= 0 &&
+           !((uint32_t)p->reserved[0] & (uint32_t)BFA_HINT_NO_SILENCE_TARGETS);
+}
 
 // shape-only bounds shared by bfa_workspace_bytes and bfa_align_batch
 struct Layout {
