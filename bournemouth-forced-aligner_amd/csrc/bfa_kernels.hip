@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
     const int b = gid >> 4, sub = gid & 15;
     // counters[] are zeroed by a memset node ahead of this kernel; one item slot per utterance, the
     // segmented planner appends more
-    if (gid == 0) a.counters[0] = a.B;
+    if (gid == 0) {
+        a.counters[0] = a.B;
+        // without the segmented mode nobody touches counters[1] during planning, and the others are first used by
+        // later kernels: the planner zeroes them itself and the launcher skips its memset
+        if (a.p.win_mask & 0x80000000u) { for (int k = 1; k < 16; ++k) a.counters[k] = 0; }
+    }
     if (b >= a.B) return; // whole 16-lane groups
     const DevParams &p = a.p;
     const int Traw = a.T_len ? a.T_len[b] : a.Tmax;
@@ -384,7 +389,8 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     }
     a.p.win_mask = wmask;
     mask |= wmask << 8;
-    (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
+    if (seg_possible) (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
+    else a.p.win_mask |= 0x80000000u; // k_plan zeroes the counters (see there)
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
