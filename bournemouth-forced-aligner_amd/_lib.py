@@ -35,7 +35,7 @@ class BfaSegment(ctypes.Structure):
 def build(force=False):
     """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    args = ["make", "-C", src_dir]
+    args = ["make", "-j%d" % max(1, min(8, os.cpu_count() or 1)), "-C", src_dir]
     if force:
         args.append("-B")
     subprocess.check_call(args)
