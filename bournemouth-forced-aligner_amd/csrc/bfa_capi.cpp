@@ -20,6 +20,8 @@ extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                                       int C, void *stream);
+extern "C" int bfa_launch_stitch(const float *win, int B, int NW, int F, int C, const float *weights, int total_frames,
+                                 float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_postprocess(const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                                       const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count,
                                       int extend, double th1, double th2, void *stream);
@@ -352,6 +354,25 @@ int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out
     if (C < 16 || C > bfa::MAX_C) return fail(h, BFA_ERR_UNSUPPORTED, "C must be in [16,128]");
     if (rows == 0) return BFA_OK;
     const int rc = bfa_launch_log_softmax(logits, ld_in, out, ld_out, rows, C, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_stitch_windows(bfa_handle h, const float *window_logits, int B, int NW, int F, int C, const float *weights,
+                       int total_frames, float *out, int64_t out_strideB, int64_t out_strideT, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!window_logits || !weights || !out || B < 0 || NW < 0 || F <= 0 || C <= 0 || total_frames < 0 ||
+        out_strideT < C)
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");
+    const int stride = F / 2;
+    // the reference raises a shape error when a window other than the last does not fit (windowing.py:144-149)
+    if (NW >= 2 && (int64_t)(NW - 2) * stride + F > total_frames)
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "a full window does not fit into total_frames");
+    if (NW > 0 && total_frames > 0 && (int64_t)(NW - 1) * stride >= total_frames)
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "the last window starts beyond total_frames");
+    if (B == 0 || total_frames == 0) return BFA_OK;
+    const int rc = bfa_launch_stitch(window_logits, B, NW, F, C, weights, total_frames, out, out_strideB, out_strideT, stream);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }

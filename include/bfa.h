@@ -169,6 +169,16 @@ int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t st
 int bfa_profile_enable(bfa_handle h, int on);
 int bfa_profile_collect(bfa_handle h, float *out_ms_host, int cap);
 
+/*
+ * Window stitching, the step in front of the path: stich_window_predictions
+ * (bournemouth_aligner/cupe2i/windowing.py:103-173, called at core.py:422-438): cosine-weighted overlap-add of
+ * per-window outputs window_logits [B, NW, F, C] into out [B, total_frames, C] with the caller's row / batch
+ * strides (in floats; out_strideT >= C, e.g. padded rows).  weights [F] (device) = cos(linspace(-pi/2, pi/2, F)) as the
+ * caller's torch computes it; total_frames as in windowing.py:121-126.  Bit-identical to the reference.
+ */
+int bfa_stitch_windows(bfa_handle h, const float *window_logits, int B, int NW, int F, int C, const float *weights,
+                       int total_frames, float *out, int64_t out_strideB, int64_t out_strideT, void *stream);
+
 /* F.log_softmax(dim=-1) of raw logits [rows,C] (core.py:898-899), torch-CPU-exact numerics */
 int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                     int C, void *stream);

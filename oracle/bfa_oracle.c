@@ -786,3 +786,48 @@ void ora_convert_to_ms(const int32_t *seg4, int n, int spectral_len, double star
         end_ms[i] = es * 1000.0f;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * stich_window_predictions, cupe2i/windowing.py:103-173.  Float32 throughout, in the reference's order:
+ * combined[t] (+)= x * w window by window (ascending), weight_sum[t] (+)= w, then combined / (weight_sum + 1e-8).
+ * The last window is cut to the frames that still fit (:152-163); stride_frames = F // 2 (:127).
+ * ---------------------------------------------------------------------------------------- */
+int ora_stitch_windows(const float *win, int B, int NW, int F, int C, const float *weights, int total_frames,
+                       float *out, long ld_out)
+{
+    if (B < 0 || NW < 0 || F <= 0 || C <= 0 || total_frames < 0 || ld_out < C) return ORA_ERR_ARG;
+    const int stride = F / 2;
+    for (int i = 0; i + 1 < NW; i++)
+        if (i * stride + F > total_frames) return ORA_ERR_ARG; /* :144-149 would raise */
+    if (NW > 0 && (NW - 1) * stride >= total_frames && total_frames > 0) return ORA_ERR_ARG; /* negative slice length */
+    float *wsum = (float *)malloc(sizeof(float) * (size_t)(total_frames > 0 ? total_frames : 1));
+    if (!wsum) return ORA_ERR_ALLOC;
+    for (int b = 0; b < B; b++) {
+        float *ob = out + (long)b * total_frames * ld_out;
+        for (int t = 0; t < total_frames; t++) {
+            wsum[t] = 0.0f;
+            for (int c = 0; c < C; c++) ob[(long)t * ld_out + c] = 0.0f;
+        }
+        for (int i = 0; i < NW; i++) {
+            const int start = i * stride;
+            int nf = F;
+            if (i == NW - 1 && start + F > total_frames) nf = total_frames - start;
+            const float *wb = win + (((long)b * NW + i) * F) * C;
+            for (int f = 0; f < nf; f++) {
+                const float w = weights[f];
+                float *o = ob + (long)(start + f) * ld_out;
+                for (int c = 0; c < C; c++) {
+                    const float prod = wb[(long)f * C + c] * w; /* full_slices[:, i] * window_weights */
+                    o[c] = o[c] + prod;                          /* combined[...] += */
+                }
+                wsum[start + f] = wsum[start + f] + w;
+            }
+        }
+        for (int t = 0; t < total_frames; t++) {
+            const float den = wsum[t] + 1e-8f; /* python float 1e-8 added to a float32 tensor */
+            for (int c = 0; c < C; c++) ob[(long)t * ld_out + c] = ob[(long)t * ld_out + c] / den;
+        }
+    }
+    free(wsum);
+    return ORA_OK;
+}

@@ -103,6 +103,13 @@ int ora_extend_soft_boundaries(const float *lp, long ldT, int Tpad, int C, int32
 void ora_convert_to_ms(const int32_t *seg4, int n, int spectral_len, double start_offset, double wav_len,
                        double sample_rate, float *start_ms, float *end_ms);
 
+/* cupe2i/windowing.py:103-173 stich_window_predictions: cosine-weighted overlap-add of per-window outputs.
+ * win [B][NW][F][C] float32 ; weights[F] = cos(linspace(-pi/2, pi/2, F)) as computed by the caller ;
+ * out [B][total_frames][ld_out >= C] (columns >= C untouched).  Returns 0, or ORA_ERR_ARG when a window that is not
+ * the last one does not fit into total_frames (the reference raises a shape error there). */
+int ora_stitch_windows(const float *win, int B, int NW, int F, int C, const float *weights, int total_frames,
+                       float *out, long ld_out);
+
 #ifdef __cplusplus
 }
 #endif

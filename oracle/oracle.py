@@ -223,3 +223,21 @@ def convert_to_ms(segs, spectral_len, start_offset, wav_len, sample_rate):
     lib().ora_convert_to_ms(_p(arr), n, int(spectral_len), ctypes.c_double(start_offset),
                             ctypes.c_double(wav_len), ctypes.c_double(sample_rate), _p(a), _p(b))
     return a, b
+
+
+def stitch_total_frames(original_audio_length, cnn_output_size, sample_rate=16000, window_size_ms=160, stride_ms=80):
+    """cupe2i/windowing.py:121-126"""
+    window_size_samples = int(window_size_ms * sample_rate / 1000)
+    stride_samples = int(stride_ms * sample_rate / 1000)
+    num_windows_total = ((original_audio_length - window_size_samples) // stride_samples) + 1
+    return (num_windows_total * cnn_output_size) // 2
+
+
+def stitch_windows(window_logits, weights, total_frames, ld_out=None):
+    """cupe2i/windowing.py:103-173 given the cosine weights and the number of output frames."""
+    w = _f32(window_logits)
+    B, NW, F, C = w.shape
+    ld = C if ld_out is None else int(ld_out)
+    out = np.zeros((B, max(int(total_frames), 0), ld), np.float32)
+    rc = lib().ora_stitch_windows(_p(w), B, NW, F, C, _p(_f32(weights)), int(total_frames), _p(out), ctypes.c_long(ld))
+    return rc, out

@@ -111,3 +111,32 @@ def test_process_sentence_plumbing(gpu_device):
         assert p["end_ms"] >= p["start_ms"] and p["target_seq_idx"] == i and 0.0 < p["confidence"] <= 1.0
         assert abs(p["start_ms"] - (5 + 9 * i) * 16.75) < 3 * 16.75
     assert res == al.process_batch(["butterfly"], [wav], do_groups=True)[0]
+
+
+def test_window_stitching_against_reference_and_oracle(gpu_device):
+    """bfa_stitch_windows vs the reference's own stich_window_predictions outputs (golden, bit patterns), with plain
+    and padded output rows, and vs the oracle on larger random shapes."""
+    import os
+    from oracle import oracle as ora
+    from bournemouth_forced_aligner_amd import stich_window_predictions, stitch_total_frames
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stitch_cases.npz"))
+    for k in range(int(z["n"])):
+        x, y = z[f"c{k}_x"], z[f"c{k}_y"]
+        alen, F, sr, wms, sms = (int(v) for v in z[f"c{k}_cfg"])
+        for pad in (None, x.shape[3] + 5):
+            got = stich_window_predictions(torch.from_numpy(x).to(gpu_device), alen, F, sr, wms, sms, row_stride=pad)
+            assert tuple(got.shape) == y.shape
+            assert (got.cpu().numpy().view(np.int32) == y.view(np.int32)).all(), f"case {k} pad {pad}"
+    rng = np.random.default_rng(12)
+    for B, NW, F, C in ((4, 61, 10, 67), (3, 124, 10, 17), (2, 33, 7, 67), (1, 2, 2, 40), (2, 9, 1, 5)):
+        alen = 16000 * (160 + 80 * (NW - 1)) // 1000
+        x = rng.normal(0, 4, size=(B, NW, F, C)).astype(np.float32)
+        total = stitch_total_frames(alen, F)
+        w = torch.cos(torch.linspace(-np.pi / 2, np.pi / 2, F)).numpy()
+        rc, exp = ora.stitch_windows(x, w, total)
+        if rc != 0:   # shapes the reference itself rejects: the library must reject them too
+            with pytest.raises(RuntimeError):
+                stich_window_predictions(torch.from_numpy(x).to(gpu_device), alen, F)
+            continue
+        got = stich_window_predictions(torch.from_numpy(x).to(gpu_device), alen, F).cpu().numpy()
+        assert (got.view(np.int32) == exp.view(np.int32)).all(), (B, NW, F, C)

@@ -137,3 +137,23 @@ def test_level2_postprocessing(ora, gold):
             np.testing.assert_allclose(conf[order], gf[:, 0], atol=2e-7, rtol=0)
             np.testing.assert_array_equal(sm[order], gf[:, 1])
             np.testing.assert_array_equal(em[order], gf[:, 2])
+
+
+def test_window_stitching_against_reference(ora):
+    """stich_window_predictions (cupe2i/windowing.py:103-173): the oracle restatement reproduces the reference's own
+    outputs bit for bit (golden vectors from tests/golden/make_golden_stitch.py); the cosine weights are the
+    reference's torch.cos values."""
+    import os
+    import torch
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stitch_cases.npz"))
+    for k in range(int(z["n"])):
+        x, y, w = z[f"c{k}_x"], z[f"c{k}_y"], z[f"c{k}_w"]
+        alen, F, sr, wms, sms = (int(v) for v in z[f"c{k}_cfg"])
+        total = ora.stitch_total_frames(alen, F, sr, wms, sms)
+        assert total == y.shape[1]
+        rc, got = ora.stitch_windows(x, w, total)
+        assert rc == 0
+        assert (got.view(np.int32) == y.view(np.int32)).all(), f"case {k}"
+        # the weights this build computes itself are the reference's
+        w2 = torch.cos(torch.linspace(-np.pi / 2, np.pi / 2, F)).numpy()
+        assert (w2.view(np.int32) == w.view(np.int32)).all()
