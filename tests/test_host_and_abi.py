@@ -168,3 +168,25 @@ def test_world_size_2_gather_on_gloo(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(os.path.join(str(tmp_path), "ok")).read() == "1"
+
+
+def test_textgrid_writer_matches_the_reference_examples():
+    """dict_to_textgrid (utils.py:152-411) against the reference's own example pairs (data files) and the
+    with-confidence / missing-tier variants its writer produces (tests/golden/make_golden_textgrid.py)."""
+    import json
+    import os
+    from bournemouth_forced_aligner_amd.textgrid import dict_to_textgrid, dict_to_textgrid_with_confidence
+    here = os.path.join(os.path.dirname(__file__), "golden", "textgrid")
+    exp = json.load(open(os.path.join(here, "expected_variants.json"), encoding="utf-8"))
+    for stem in ("LJ001-0001", "LJ001-0002"):
+        d = json.load(open(os.path.join(here, stem + ".vs.json"), encoding="utf-8"))
+        assert dict_to_textgrid(d) == open(os.path.join(here, stem + ".TextGrid"), encoding="utf-8").read()
+        assert dict_to_textgrid(d, include_confidence=True) == exp[stem]
+        assert dict_to_textgrid_with_confidence(d) == exp[stem]
+        d2 = {"segments": [dict(d["segments"][0])]}
+        d2["segments"][0].pop("words_ts", None)
+        assert dict_to_textgrid(d2) == exp[stem + ":no_words"]
+        assert dict_to_textgrid(d2, include_confidence=True) == exp[stem + ":no_words:conf"]
+    assert dict_to_textgrid({"segments": [{"start": 0.0, "end": 2.5}]}) == exp["empty"]
+    with pytest.raises(ValueError):
+        dict_to_textgrid({"segments": []})
