@@ -57,6 +57,50 @@ __global__ __launch_bounds__(256) void k_stitch(const float *__restrict__ win, i
     }
 }
 
+// Even frames-per-window (the model's: 10): stride = F/2, so at most two windows cover a frame -- i1 = t / stride and
+// i0 = i1 - 1 -- and both loads can be issued unconditionally (clamped addresses), four elements per thread in flight.
+__global__ __launch_bounds__(256) void k_stitch_even(const float *__restrict__ win, int NW, int F, int C,
+                                                     const float *__restrict__ weights, int total_frames,
+                                                     float *__restrict__ out, int64_t oB, int64_t oT)
+{
+    const int stride = F / 2;
+    const int b = blockIdx.y;
+    const int n = total_frames * C;
+    const float *wb = win + (int64_t)b * NW * F * C;
+    float *ob = out + (int64_t)b * oB;
+    const int last_nf = min(F, total_frames - (NW - 1) * stride); // frames the last window contributes
+    constexpr int U = 4;
+    for (int e0 = (blockIdx.x * U) * blockDim.x + threadIdx.x; e0 < n; e0 += gridDim.x * U * blockDim.x) {
+        float x0[U], x1[U], w0[U], w1[U];
+        bool h0[U], h1[U];
+        int t_[U], c_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u * (int)blockDim.x, n - 1);
+            const int t = e / C, c = e - t * C;
+            t_[u] = t; c_[u] = c;
+            const int i1 = t / stride, f1 = t - i1 * stride; // f1 < stride
+            const int i0 = i1 - 1, f0 = f1 + stride;         // f0 < F
+            h1[u] = i1 <= NW - 1 && (i1 < NW - 1 || f1 < last_nf);
+            h0[u] = i0 >= 0 && i0 <= NW - 1 && (i0 < NW - 1 || f0 < last_nf);
+            const int j1 = min(i1, NW - 1), j0 = min(max(i0, 0), NW - 1);
+            x1[u] = wb[(j1 * F + f1) * C + c];
+            x0[u] = wb[(j0 * F + f0) * C + c];
+            w1[u] = weights[f1];
+            w0[u] = weights[f0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e0 + u * (int)blockDim.x >= n) break;
+            const float p0 = x0[u] * w0[u], p1 = x1[u] * w1[u];
+            float comb = 0.0f, wsum = 0.0f; // ascending window order: i0, then i1
+            if (h0[u]) { comb = comb + p0; wsum = wsum + w0[u]; }
+            if (h1[u]) { comb = comb + p1; wsum = wsum + w1[u]; }
+            ob[(int64_t)t_[u] * oT + c_[u]] = comb / (wsum + 1e-8f);
+        }
+    }
+}
+
 } // namespace bfa
 
 extern "C" int bfa_launch_stitch(const float *win, int B, int NW, int F, int C, const float *weights, int total_frames,
@@ -70,8 +114,12 @@ extern "C" int bfa_launch_stitch(const float *win, int B, int NW, int F, int C, 
     if (bx < 1) bx = 1;
     for (int b0 = 0; b0 < B; b0 += 65535) { // gridDim.y limit
         const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
-        hipLaunchKernelGGL(bfa::k_stitch, dim3((unsigned)bx, (unsigned)nb), dim3(256), 0, stream,
-                           win + (int64_t)b0 * NW * F * C, nb, NW, F, C, weights, total_frames, out + (int64_t)b0 * oB, oB, oT);
+        if ((F & 1) == 0 && NW > 0)
+            hipLaunchKernelGGL(bfa::k_stitch_even, dim3((unsigned)bx, (unsigned)nb), dim3(256), 0, stream,
+                               win + (int64_t)b0 * NW * F * C, NW, F, C, weights, total_frames, out + (int64_t)b0 * oB, oB, oT);
+        else
+            hipLaunchKernelGGL(bfa::k_stitch, dim3((unsigned)bx, (unsigned)nb), dim3(256), 0, stream,
+                               win + (int64_t)b0 * NW * F * C, nb, NW, F, C, weights, total_frames, out + (int64_t)b0 * oB, oB, oT);
     }
     return (int)hipGetLastError();
 }
