@@ -449,11 +449,17 @@ extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream_)
     return (int)hipGetLastError();
 }
 
+extern "C" int bfa_launch_log_softmax3_nk2(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows, int C, hipStream_t stream);
+extern "C" int bfa_launch_log_softmax3_nk5(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows, int C, hipStream_t stream);
+
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                                       int C, void *stream_)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
+    // the two head widths take the sixteen-rows-per-pass block of the alignment producer (bfa_dp3.inc)
+    if (C == 17 && bfa_launch_log_softmax3_nk2(in, ld_in, out, ld_out, rows, C, stream)) return (int)hipGetLastError();
+    if (C == 67 && bfa_launch_log_softmax3_nk5(in, ld_in, out, ld_out, rows, C, stream)) return (int)hipGetLastError();
     const int nk = (C + 15) / 16;
     int64_t blocks = (rows + 15) / 16;
     if (blocks > 8192) blocks = 8192;
