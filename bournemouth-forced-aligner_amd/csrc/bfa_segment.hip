@@ -89,176 +89,316 @@ __device__ int detect_silence(const float *ps, int Tx, float thr, int k, int32_t
     return n;
 }
 
+// The same on a P(SIL) vector staged in LDS, by the whole wavefront (all lanes follow the same control flow).  The
+// running float64 sum of torch.cumsum stays serial (its additions are not reorderable), but it is walked once per
+// call -- cs[i] = float32(cumsum[i]) goes to LDS -- and the window averages, the threshold test and the run
+// bookkeeping work on 64 windows at a time (ballot + bit scans).
+__device__ int detect_silence_w(const float *ps, int Tx, float thr, int k, int32_t *out, int cap, float *cs, int lane)
+{
+    if (Tx < k) return 0; // :499
+    if (k < 1) k = 1;
+    const int nwin = (k > 1) ? (Tx - k + 1) : Tx;
+    if (k > 1) {
+        // cumsum[i], float64 accumulate (:508): 64 values per LDS round trip, handed from lane to lane with readlane
+        // so that no memory latency sits in the serial chain; lane j keeps cs[base + j]
+        double acc = 0.0;
+        for (int base = 0; base < Tx; base += 64) {
+            const float x = (base + lane < Tx) ? ps[base + lane] : 0.0f;
+            float mine = 0.0f;
+            const int nv = min(64, Tx - base);
+            if (nv == 64) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+                    mine = (lane == j) ? (float)acc : mine;
+                }
+            } else {
+                for (int j = 0; j < nv; ++j) {
+                    acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+                    mine = (lane == j) ? (float)acc : mine;
+                }
+            }
+            if (base + lane < Tx) cs[base + lane] = mine;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    int n = 0, start = 0;
+    bool in_sil = false;
+    for (int base = 0; base < nwin; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < nwin;
+        float avg = 0.0f;
+        if (valid) {
+            if (k > 1) avg = (cs[i + k - 1] - (i > 0 ? cs[i - 1] : 0.0f)) / (float)k; // :510
+            else avg = ps[i];
+        }
+        const int nv = min(64, nwin - base);
+        const unsigned long long vmask = (nv == 64) ? ~0ull : ((1ull << nv) - 1ull);
+        const unsigned long long bits = __ballot(valid && avg >= thr) & vmask; // :517
+        int pos = 0;
+        while (pos < nv) {
+            const unsigned long long rest = (in_sil ? (~bits & vmask) : bits) >> pos; // next change of state
+            if (rest == 0ull) break;
+            const int j = pos + __builtin_ctzll(rest);
+            if (!in_sil) { in_sil = true; start = base + j; }
+            else {
+                in_sil = false;
+                int e = base + j + k - 1; // :530-531
+                if (e > Tx) e = Tx;
+                if (e - start >= k) { if (n >= cap) return -1; if (lane == 0) { out[2 * n] = start; out[2 * n + 1] = e; } ++n; }
+            }
+            pos = j + 1;
+        }
+    }
+    if (in_sil && Tx - start >= k) { if (n >= cap) return -1; if (lane == 0) { out[2 * n] = start; out[2 * n + 1] = Tx; } ++n; } // :536-539
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n;
+}
+
 struct SegRec { int32_t a0, a1, t0, t1, is_sil; };
 
-__global__ void k_plan_seg(AlignArgs a)
-{
-    const DevParams &p = a.p;
-    const int n_cand = a.counters[1];
-    for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n_cand; ci += gridDim.x * blockDim.x) {
-        const int b = a.cand[ci];
-        const int T = a.uT[b], S = a.uS[b];
-        const int32_t *tok = a.tokens + (int64_t)b * a.Smax;
-        const float *ps = a.psil + (int64_t)b * a.Tmax;
-        const int fallback_mode = -1 - a.umode[b];
-        // scratch carve
-        int32_t *scr = a.seg_scratch + (int64_t)b * a.seg_scratch_per_utt;
-        int32_t *groups = scr; scr += 2 * (a.Smax + 2);
-        int32_t *aud = scr; scr += 2 * (a.Tmax + 2);
-        int32_t *sub = scr; scr += 2 * (a.Tmax + 2);
-        int32_t *match = scr; scr += 2 * (a.Smax + 2);
-        SegRec *segs = (SegRec *)scr;
-        const int aud_cap = a.Tmax + 2;
+// the reference's serial control flow for one candidate utterance (run by one lane; `ps` may point into LDS)
+// planner scratch: target SIL groups, audio silences, sub-silences of a piece, matches, segment records
+struct PlanScratch {
+    int32_t *groups, *aud, *sub, *match;
+    SegRec *segs;
+    int aud_cap;
+    float *cs; // LDS, cooperative mode only
+};
 
-        bool ok = true;
-        // ---- _find_target_sil_groups :203-224
-        int ng = 0;
-        for (int i = 0; i < S;) {
-            if (tok[i] == p.sil) { const int st = i; while (i < S && tok[i] == p.sil) ++i; groups[2 * ng] = st; groups[2 * ng + 1] = i; ++ng; }
-            else ++i;
+// COOP: executed by every lane of the wavefront with identical control flow (all decisions depend on wave-uniform
+// data); scratch lives in LDS, the heavy loops are lane-parallel and global side effects come from lane 0.
+// !COOP: executed by lane 0 alone (utterances too large for the LDS arrays).
+template <bool COOP>
+__device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const PlanScratch &sc, int lane)
+{
+    const bool writer = !COOP || lane == 0;
+    auto silences = [&](const float *x, int Tx, float thr, int k, int32_t *out, int cap) {
+        if (COOP) return detect_silence_w(x, Tx, thr, k, out, cap, sc.cs, lane);
+        return detect_silence(x, Tx, thr, k, out, cap);
+    };
+    const DevParams &p = a.p;
+    const int T = a.uT[b], S = a.uS[b];
+    const int32_t *tok = a.tokens + (int64_t)b * a.Smax;
+    const int fallback_mode = -1 - a.umode[b];
+    int32_t *groups = sc.groups, *aud = sc.aud, *sub = sc.sub, *match = sc.match;
+    SegRec *segs = sc.segs;
+    const int aud_cap = sc.aud_cap;
+
+    bool ok = true;
+    // ---- _find_target_sil_groups :203-224
+    int ng = 0;
+    for (int i = 0; i < S;) {
+        if (tok[i] == p.sil) { const int st = i; while (i < S && tok[i] == p.sil) ++i; groups[2 * ng] = st; groups[2 * ng + 1] = i; ++ng; }
+        else ++i;
+    }
+    if (ng == 0) ok = false; // :293-295
+    int mf = p.anchors, na = 0;
+    if (ok) { // :296-308
+        na = silences(ps, T, 0.9f, mf, aud, aud_cap);
+        if (na == 0 && S > 200) {
+            double nt = 1.0 - (0.09 * (double)mf);
+            if (nt < 0.05) nt = 0.05;
+            na = silences(ps, T, (float)nt, mf, aud, aud_cap);
         }
-        if (ng == 0) ok = false; // :293-295
-        int mf = p.anchors, na = 0;
-        if (ok) { // :296-308
-            na = detect_silence(ps, T, 0.9f, mf, aud, aud_cap);
-            if (na == 0 && S > 200) {
-                double nt = 1.0 - (0.09 * (double)mf);
-                if (nt < 0.05) nt = 0.05;
-                na = detect_silence(ps, T, (float)nt, mf, aud, aud_cap);
+        if (na == 0 && S > 200 && mf > 3) { mf = 3; na = silences(ps, T, 0.9f, mf, aud, aud_cap); }
+        if (na <= 0) ok = false; // :315-320
+    }
+    // ---- _match_silences :226-266
+    int nm = 0;
+    if (ok) {
+        int audio_idx = 0;
+        for (int gi = 0; gi < ng; ++gi) {
+            const double tp = (double)(groups[2 * gi] + groups[2 * gi + 1]) / 2.0 / (double)S;
+            int best = -1;
+            double bd = __builtin_inf();
+            for (int ai = audio_idx; ai < na; ++ai) {
+                const double ap = (double)(aud[2 * ai] + aud[2 * ai + 1]) / 2.0 / (double)T;
+                const double d = __builtin_fabs(tp - ap);
+                if (d < bd) { bd = d; best = ai; }
+                else if (d > bd) break;
             }
-            if (na == 0 && S > 200 && mf > 3) { mf = 3; na = detect_silence(ps, T, 0.9f, mf, aud, aud_cap); }
-            if (na <= 0) ok = false; // :315-320
+            if (best >= 0 && bd < 0.3) { match[2 * nm] = gi; match[2 * nm + 1] = best; ++nm; audio_idx = best + 1; }
         }
-        // ---- _match_silences :226-266
-        int nm = 0;
-        if (ok) {
-            int audio_idx = 0;
-            for (int gi = 0; gi < ng; ++gi) {
-                const double tp = (double)(groups[2 * gi] + groups[2 * gi + 1]) / 2.0 / (double)S;
-                int best = -1;
-                double bd = __builtin_inf();
-                for (int ai = audio_idx; ai < na; ++ai) {
-                    const double ap = (double)(aud[2 * ai] + aud[2 * ai + 1]) / 2.0 / (double)T;
-                    const double d = __builtin_fabs(tp - ap);
-                    if (d < bd) { bd = d; best = ai; }
-                    else if (d > bd) break;
-                }
-                if (best >= 0 && bd < 0.3) { match[2 * nm] = gi; match[2 * nm + 1] = best; ++nm; audio_idx = best + 1; }
-            }
-            if (nm == 0) ok = false; // :324-325
+        if (nm == 0) ok = false; // :324-325
+    }
+    // ---- segment list :328-354 and merge :357-369
+    int ns = 0;
+    if (ok) {
+        int pa = 0, pt = 0;
+        for (int i = 0; i < nm; ++i) {
+            const int tg0 = groups[2 * match[2 * i]], tg1 = groups[2 * match[2 * i] + 1];
+            const int as0 = aud[2 * match[2 * i + 1]], as1 = aud[2 * match[2 * i + 1] + 1];
+            if (pa < as0 && pt < tg0) segs[ns++] = SegRec{pa, as0, pt, tg0, 0};
+            else if (pa < as0) segs[ns++] = SegRec{pa, as0, pt, pt, 0};
+            segs[ns++] = SegRec{as0, as1, tg0, tg1, 1};
+            pa = as1; pt = tg1;
         }
-        // ---- segment list :328-354 and merge :357-369
-        int ns = 0;
-        if (ok) {
-            int pa = 0, pt = 0;
-            for (int i = 0; i < nm; ++i) {
-                const int tg0 = groups[2 * match[2 * i]], tg1 = groups[2 * match[2 * i] + 1];
-                const int as0 = aud[2 * match[2 * i + 1]], as1 = aud[2 * match[2 * i + 1] + 1];
-                if (pa < as0 && pt < tg0) segs[ns++] = SegRec{pa, as0, pt, tg0, 0};
-                else if (pa < as0) segs[ns++] = SegRec{pa, as0, pt, pt, 0};
-                segs[ns++] = SegRec{as0, as1, tg0, tg1, 1};
-                pa = as1; pt = tg1;
-            }
-            if (pa < T && pt < S) segs[ns++] = SegRec{pa, T, pt, S, 0};
-            else if (pa < T) segs[ns++] = SegRec{pa, T, pt, pt, 0};
-            int nmrg = 0;
-            for (int i = 0; i < ns; ++i) {
-                const SegRec s = segs[i];
-                const int nf = s.a1 - s.a0, np = s.t1 - s.t0;
-                if (!s.is_sil && np > 0 && nf < 20 && nmrg > 0) { // min_speech_frames = 20
-                    segs[nmrg - 1].a1 = s.a1; segs[nmrg - 1].t1 = s.t1; segs[nmrg - 1].is_sil = 0;
-                } else segs[nmrg++] = s;
-            }
-            ns = nmrg;
+        if (pa < T && pt < S) segs[ns++] = SegRec{pa, T, pt, S, 0};
+        else if (pa < T) segs[ns++] = SegRec{pa, T, pt, pt, 0};
+        int nmrg = 0;
+        for (int i = 0; i < ns; ++i) {
+            const SegRec s = segs[i];
+            const int nf = s.a1 - s.a0, np = s.t1 - s.t0;
+            if (!s.is_sil && np > 0 && nf < 20 && nmrg > 0) { // min_speech_frames = 20
+                segs[nmrg - 1].a1 = s.a1; segs[nmrg - 1].t1 = s.t1; segs[nmrg - 1].is_sil = 0;
+            } else segs[nmrg++] = s;
         }
-        // ---- validation pass: every speech segment must fit (:427-429), count the pieces
-        int npieces = 0;
-        int too_large = 0;
-        if (ok) {
-            for (int i = 0; i < ns; ++i) {
-                const SegRec s = segs[i];
-                const int n = s.a1 - s.a0;
-                if (n <= 0) continue;
-                ++npieces;
-                const int nt = s.t1 - s.t0;
-                if (s.is_sil || nt == 0) continue;
-                const int psx = max(0, s.a0 - 3), pex = min(T, s.a1 + 3);
-                const int Ts = pex - psx;
-                int stride = 4;
-                if ((double)(stride * nt + 1) > (double)Ts * 0.9) stride = 3;
-                if ((double)(stride * nt + 1) > (double)Ts * 0.8) stride = 2;
-                const int L = stride * nt + 1;
-                if ((double)L > (double)Ts * 1.2) { ok = false; break; }
-                if (L > BIG_MAX_L) too_large = 1;
-            }
-            if (npieces == 0) ok = false; // :454-455
-        }
-        if (!ok) { a.umode[b] = fallback_mode; continue; }
-        if (too_large) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; continue; }
-        // pieces are CONCATENATED (:453-467): audio silences may overlap, so a piece's output position is the
-        // running length, not its audio position; the result is truncated / blank-padded to T frames
-        npieces += 1; // room for the blank tail
-        const int base = atomicAdd(&a.counters[0], npieces);
-        if (base + npieces > a.item_cap) { // cannot happen with the documented workspace size
-            a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; continue;
-        }
-        // ---- emit one item per piece (:377-451)
-        int64_t bp_off = (int64_t)b * a.bp_per_utt;
-        int anch_used = 0;
-        uint8_t *apool = a.anchor + (int64_t)b * a.anchor_per_utt;
-        int slot = base;
-        int w = 0; // frames written so far
+        ns = nmrg;
+    }
+    // ---- validation pass: every speech segment must fit (:427-429), count the pieces
+    int npieces = 0;
+    int too_large = 0;
+    if (ok) {
         for (int i = 0; i < ns; ++i) {
             const SegRec s = segs[i];
             const int n = s.a1 - s.a0;
             if (n <= 0) continue;
-            Item it;
-            it.kind = ITEM_NONE; it.utt = b; it.row0 = s.a0; it.Ts = n; it.tok0 = s.t0; it.nt = s.t1 - s.t0; it.stride = 0;
-            it.L = 0; it.bw = 0; it.out0 = s.a0; it.nout = n; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.pad_ = 0;
-            it.bp_off = bp_off;
-            if (s.is_sil) it.kind = ITEM_FILL_SIL;          // :382-397
-            else if (it.nt == 0) it.kind = ITEM_FILL_BLANK; // :409-412
-            else {
-                const int psx = max(0, s.a0 - 3), pex = min(T, s.a1 + 3); // :401-403
-                const int Ts = pex - psx;
-                int stride = 4; // :423-426
-                if ((double)(stride * it.nt + 1) > (double)Ts * 0.9) stride = 3;
-                if ((double)(stride * it.nt + 1) > (double)Ts * 0.8) stride = 2;
-                const int L = stride * it.nt + 1;
-                it.kind = ITEM_DP; it.row0 = psx; it.Ts = Ts; it.stride = stride; it.L = L;
-                it.bw = (L > 60) ? ((L / 3 > 30) ? L / 3 : 30) : 0; // :441
-                it.pad_left = s.a0 - psx;
-                bp_off += bp_dwords(Ts, L);
-                // sub-silences of the padded slice get +5 on blank and a re-normalisation, once per
-                // (possibly overlapping) detected segment (:415-419, :543-561)
-                const int nsub = detect_silence(ps + psx, Ts, 0.8f, mf, sub, aud_cap);
-                if (nsub > 0 && anch_used + Ts <= a.anchor_per_utt) {
-                    uint8_t *ac = apool + anch_used;
+            ++npieces;
+            const int nt = s.t1 - s.t0;
+            if (s.is_sil || nt == 0) continue;
+            const int psx = max(0, s.a0 - 3), pex = min(T, s.a1 + 3);
+            const int Ts = pex - psx;
+            int stride = 4;
+            if ((double)(stride * nt + 1) > (double)Ts * 0.9) stride = 3;
+            if ((double)(stride * nt + 1) > (double)Ts * 0.8) stride = 2;
+            const int L = stride * nt + 1;
+            if ((double)L > (double)Ts * 1.2) { ok = false; break; }
+            if (L > BIG_MAX_L) too_large = 1;
+        }
+        if (npieces == 0) ok = false; // :454-455
+    }
+    if (!ok) { if (writer) a.umode[b] = fallback_mode; return; }
+    if (too_large) { if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; } return; }
+    // pieces are CONCATENATED (:453-467): audio silences may overlap, so a piece's output position is the
+    // running length, not its audio position; the result is truncated / blank-padded to T frames
+    npieces += 1; // room for the blank tail
+    int base = writer ? atomicAdd(&a.counters[0], npieces) : 0;
+    if (COOP) base = __builtin_amdgcn_readfirstlane(base);
+    if (base + npieces > a.item_cap) { // cannot happen with the documented workspace size
+        if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; }
+        return;
+    }
+    // ---- emit one item per piece (:377-451)
+    int64_t bp_off = (int64_t)b * a.bp_per_utt;
+    int anch_used = 0;
+    uint8_t *apool = a.anchor + (int64_t)b * a.anchor_per_utt;
+    int slot = base;
+    int w = 0; // frames written so far
+    for (int i = 0; i < ns; ++i) {
+        const SegRec s = segs[i];
+        const int n = s.a1 - s.a0;
+        if (n <= 0) continue;
+        Item it;
+        it.kind = ITEM_NONE; it.utt = b; it.row0 = s.a0; it.Ts = n; it.tok0 = s.t0; it.nt = s.t1 - s.t0; it.stride = 0;
+        it.L = 0; it.bw = 0; it.out0 = s.a0; it.nout = n; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.pad_ = 0;
+        it.bp_off = bp_off;
+        if (s.is_sil) it.kind = ITEM_FILL_SIL;          // :382-397
+        else if (it.nt == 0) it.kind = ITEM_FILL_BLANK; // :409-412
+        else {
+            const int psx = max(0, s.a0 - 3), pex = min(T, s.a1 + 3); // :401-403
+            const int Ts = pex - psx;
+            int stride = 4; // :423-426
+            if ((double)(stride * it.nt + 1) > (double)Ts * 0.9) stride = 3;
+            if ((double)(stride * it.nt + 1) > (double)Ts * 0.8) stride = 2;
+            const int L = stride * it.nt + 1;
+            it.kind = ITEM_DP; it.row0 = psx; it.Ts = Ts; it.stride = stride; it.L = L;
+            it.bw = (L > 60) ? ((L / 3 > 30) ? L / 3 : 30) : 0; // :441
+            it.pad_left = s.a0 - psx;
+            bp_off += bp_dwords(Ts, L);
+            // sub-silences of the padded slice get +5 on blank and a re-normalisation, once per
+            // (possibly overlapping) detected segment (:415-419, :543-561)
+            const int nsub = silences(ps + psx, Ts, 0.8f, mf, sub, aud_cap);
+            if (nsub > 0 && anch_used + Ts <= a.anchor_per_utt) {
+                uint8_t *ac = apool + anch_used;
+                if (COOP) { // one frame per lane: how many detected segments cover it
+                    for (int f = lane; f < Ts; f += 64) {
+                        int cnt = 0;
+                        for (int q = 0; q < nsub; ++q) cnt += (f >= sub[2 * q] && f < sub[2 * q + 1]) ? 1 : 0;
+                        ac[f] = (uint8_t)cnt;
+                    }
+                } else {
                     for (int f = 0; f < Ts; ++f) ac[f] = 0;
                     for (int q = 0; q < nsub; ++q)
                         for (int f = sub[2 * q]; f < sub[2 * q + 1]; ++f) ac[f] = (uint8_t)(ac[f] + 1);
-                    it.anch_off = anch_used;
-                    anch_used += Ts;
                 }
+                it.anch_off = anch_used;
+                anch_used += Ts;
             }
-            it.out0 = w;
-            it.nout = min(n, max(0, T - w));
-            w += n;
-            a.items[slot++] = it;
         }
-        {   // :461-464 pad with blank / -1 up to T (also fills unused reserved slots)
-            Item it;
-            it.kind = (w < T) ? ITEM_FILL_BLANK : ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = 0; it.tok0 = 0; it.nt = 0;
-            it.stride = 0; it.L = 0; it.bw = 0; it.out0 = min(w, T); it.nout = max(0, T - w); it.pad_left = 0;
-            it.final_state = 0; it.anch_off = -1; it.win = 0; it.pad_ = 0; it.bp_off = 0;
-            while (slot < base + npieces) a.items[slot++] = it;
-        }
+        it.out0 = w;
+        it.nout = min(n, max(0, T - w));
+        w += n;
+        if (writer) a.items[slot] = it;
+        ++slot;
+    }
+    {   // :461-464 pad with blank / -1 up to T (also fills unused reserved slots)
+        Item it;
+        it.kind = (w < T) ? ITEM_FILL_BLANK : ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = 0; it.tok0 = 0; it.nt = 0;
+        it.stride = 0; it.L = 0; it.bw = 0; it.out0 = min(w, T); it.nout = max(0, T - w); it.pad_left = 0;
+        it.final_state = 0; it.anch_off = -1; it.win = 0; it.pad_ = 0; it.bp_off = 0;
+        while (slot < base + npieces) { if (writer) a.items[slot] = it; ++slot; }
+    }
+    if (writer) {
         a.items[b].kind = ITEM_NONE; // the standard-mode fallback item is not needed
         a.umode[b] = BFA_MODE_SEGMENTED;
     }
 }
 
+// one wavefront per candidate: the lanes stage its P(SIL) vector in LDS and lane 0 plans with LDS scratch (the
+// planner walks these arrays several times with serial, dependent accesses -- from global memory that latency was the
+// whole kernel time).  Utterances whose worst-case counts exceed the LDS arrays use the global scratch instead.
+constexpr int PLAN_LDS_FRAMES = 2048;
+constexpr int PLAN_LDS_SILS = 128;  // audio silences / sub-silences (pairs)
+constexpr int PLAN_LDS_GROUPS = 64; // target SIL groups / matches (pairs)
+
+__global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a)
+{
+    __shared__ float sps[PLAN_LDS_FRAMES], scs[PLAN_LDS_FRAMES];
+    __shared__ int32_t s_aud[2 * PLAN_LDS_SILS], s_sub[2 * PLAN_LDS_SILS];
+    __shared__ int32_t s_groups[2 * PLAN_LDS_GROUPS], s_match[2 * PLAN_LDS_GROUPS];
+    __shared__ SegRec s_segs[2 * PLAN_LDS_GROUPS + 4];
+    const int lane = threadIdx.x & 63;
+    const int n_cand = a.counters[1];
+    for (int ci = blockIdx.x; ci < n_cand; ci += gridDim.x) {
+        const int b = a.cand[ci];
+        const int T = a.uT[b], S = a.uS[b];
+        const float *ps = a.psil + (int64_t)b * a.Tmax;
+        // a silence run is at least min_k frames long (anchors, or 3 on the S > 200 retry): T / min_k + 1 runs at most;
+        // SIL groups alternate with other tokens: (S + 1) / 2 at most
+        const int min_k = (S > 200 && a.p.anchors > 3) ? 3 : (a.p.anchors > 0 ? a.p.anchors : 1);
+        const bool coop = T <= PLAN_LDS_FRAMES && (T / min_k + 2 <= PLAN_LDS_SILS) && ((S + 1) / 2 + 1 <= PLAN_LDS_GROUPS);
+        __builtin_amdgcn_wave_barrier(); // the previous candidate's readers are done
+        PlanScratch sc;
+        if (coop) { // wave-uniform
+            for (int t = lane; t < T; t += 64) sps[t] = ps[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            sc.groups = s_groups; sc.aud = s_aud; sc.sub = s_sub; sc.match = s_match; sc.segs = s_segs;
+            sc.aud_cap = PLAN_LDS_SILS; sc.cs = scs;
+            plan_candidate<true>(a, b, sps, sc, lane);
+        } else if (lane == 0) {
+            int32_t *scr = a.seg_scratch + (int64_t)b * a.seg_scratch_per_utt;
+            sc.groups = scr; scr += 2 * (a.Smax + 2);
+            sc.aud = scr; scr += 2 * (a.Tmax + 2);
+            sc.sub = scr; scr += 2 * (a.Tmax + 2);
+            sc.match = scr; scr += 2 * (a.Smax + 2);
+            sc.segs = (SegRec *)scr;
+            sc.aud_cap = a.Tmax + 2; sc.cs = nullptr;
+            plan_candidate<false>(a, b, ps, sc, lane);
+        }
+    }
+}
+
 } // namespace bfa
+
+extern "C" int bfa_launch_silprob3_nk2(const bfa::AlignArgs *args, hipStream_t stream);
+extern "C" int bfa_launch_silprob3_nk5(const bfa::AlignArgs *args, hipStream_t stream);
 
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream)
 {
@@ -266,8 +406,11 @@ extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t 
     const AlignArgs &a = *args;
     const int nk = (a.C + 15) / 16;
     const int grid = 2048;
-    if (nk <= 2) hipLaunchKernelGGL(k_silprob<2>, dim3(grid), dim3(64), 0, stream, a);
+    // the two head widths take the sixteen-rows-per-pass block (bfa_dp3.inc)
+    if (a.C == 17 && bfa_launch_silprob3_nk2(&a, stream)) { /* launched */ }
+    else if (a.C == 67 && bfa_launch_silprob3_nk5(&a, stream)) { /* launched */ }
+    else if (nk <= 2) hipLaunchKernelGGL(k_silprob<2>, dim3(grid), dim3(64), 0, stream, a);
     else if (nk <= 5) hipLaunchKernelGGL(k_silprob<5>, dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(k_silprob<8>, dim3(grid), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(k_plan_seg, dim3((a.B + 63) / 64 < 1024 ? (a.B + 63) / 64 : 1024), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(k_plan_seg, dim3(a.B < 16384 ? a.B : 16384), dim3(64), 0, stream, a);
 }

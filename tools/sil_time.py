@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""tools/sil_time.py -- step time of the silence-anchored (segmented) mode: headline shape with SIL at ~1/12 of the
+target positions and 12-40-frame planted silences (SURVEY.md section 8(d) "-sil" variant), parity sample included."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from oracle import oracle as ora  # noqa: E402
+from bournemouth_forced_aligner_amd import AlignmentUtils  # noqa: E402
+
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(5)
+C, blank, T, S, NB = 67, 66, 1000, 40, 512
+lps, toks = [], []
+for _ in range(NB):
+    lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=9.0, sil_rate=1 / 12, sil_len=(12, 40))
+    lps.append(lp); toks.append(tk)
+lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+rep = 8
+lpd = torch.from_numpy(lp).to(dev).repeat(rep, 1, 1)
+tkd = torch.from_numpy(tk).repeat(rep, 1)
+Tl = np.tile(T_len, rep); Sl = np.tile(S_len, rep)
+au = AlignmentUtils(blank, 0)
+for _ in range(3):
+    res = au.decode_alignments_device(lpd, tkd, Tl, Sl)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    res = au.decode_alignments_device(lpd, tkd, Tl, Sl)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 10 * 1e3
+md = res.mode.cpu().numpy()
+exp = ora.decode_alignments(lp[:64], tk[:64], T_len[:64], S_len[:64], ora.make_params(blank, 0), seg_cap=res.segs.shape[1])
+gs, gc = res.segs[:64].cpu().numpy(), res.seg_count[:64].cpu().numpy()
+mism = sum(int(gc[b] != exp["seg_count"][b] or not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all()) for b in range(64))
+print(f"B={NB * rep} T={T} S={S} with SIL: {ms:.3f} ms per step = {NB * rep * T / ms / 1e6:.2f} G frames/s; "
+      f"segmented utterances {int((md == 1).sum())}/{len(md)}; parity sample mismatches {mism}/64")
