@@ -114,9 +114,13 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
         const int L = stride * S + 1;
         it.stride = stride;
         it.L = L;
+        bool fallback_short = false;
         if (L > T) {
-            if (T < S) { status = BFA_ITEM_TOO_SHORT; it.kind = ITEM_FILL_BLANK; } // :161-165
-            else { it.kind = ITEM_FILL_PROP; mode = BFA_MODE_PROPORTIONAL; }      // :166-176
+            if (T < S) { // :161-165 -- but the segmented attempt comes first (:131-141): only its failure is the error
+                it.kind = ITEM_FILL_BLANK;
+                if (seg_candidate && status == BFA_ITEM_OK) { fallback_short = true; mode = BFA_FALLBACK_TOO_SHORT; }
+                else status = BFA_ITEM_TOO_SHORT;
+            } else { it.kind = ITEM_FILL_PROP; mode = BFA_MODE_PROPORTIONAL; }      // :166-176
         } else {
             it.kind = ITEM_DP;
             it.bw = band_standard(L);
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
             const int rw = win_class_for(L, it.bw, T); // band narrow enough (and the utterance short enough) for the window?
             if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
         }
+        (void)fallback_short;
         if (seg_candidate && status == BFA_ITEM_OK) { // k_plan_segmented decides (it may keep this fallback)
             mode = -1 - mode;
             a.cand[atomicAdd(&a.counters[1], 1)] = b;

@@ -272,7 +272,13 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
         }
         if (npieces == 0) ok = false; // :454-455
     }
-    if (!ok) { if (writer) a.umode[b] = fallback_mode; return; }
+    if (!ok) { // keep the standard-mode fallback item -- which may be the "audio too short" error (:161-165)
+        if (writer) {
+            if (fallback_mode == BFA_FALLBACK_TOO_SHORT) { a.status[b] = BFA_ITEM_TOO_SHORT; a.umode[b] = BFA_MODE_EMPTY; }
+            else a.umode[b] = fallback_mode;
+        }
+        return;
+    }
     if (too_large) { if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; } return; }
     // pieces are CONCATENATED (:453-467): audio silences may overlap, so a piece's output position is the
     // running length, not its audio position; the result is truncated / blank-padded to T frames

@@ -105,6 +105,7 @@ __host__ __device__ inline int r_class_for_L(int L)
 // CTC paths longer than 16 states x 64 lanes are split over the wavefronts of one workgroup (k_dp_big): wave w owns
 // states [1024 w, 1024 w + 1024), 16 per lane; backpointers row-major, [frame][ceil(L/16)] dwords, dword g = states
 // 16g..16g+15, 2 bits each (LSB first).
+constexpr int BFA_FALLBACK_TOO_SHORT = 4; // planner-internal umode: the standard-mode fallback of a segmented candidate is the T < S error
 constexpr int FINAL_NOT_COMPUTED = -2; // Item::final_state until a K1 kernel has taken the item (K2 reports the rest)
 constexpr int BIG_WAVES = 8;
 constexpr int BIG_MAX_L = 1024 * BIG_WAVES;

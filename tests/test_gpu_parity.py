@@ -241,10 +241,11 @@ def test_segmented_mode_with_pieces_beyond_1024_states(ora, gpu_device):
 
 def test_soak_regressions(ora, gpu_device):
     """Cases the randomized soak (tools/soak.py) found: a silence segment whose SIL indices are spread over the whole
-    segment although the concatenation is cut off at T; one with more SIL tokens than frames (empty index ranges)."""
+    segment although the concatenation is cut off at T; one with more SIL tokens than frames (empty index ranges); T < S
+    where the segmented attempt succeeds, so that the "audio too short" error of the standard mode never fires."""
     import os
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_regressions.npz"))
-    for name in ("sil_cut_at_T", "more_sil_tokens_than_frames"):
+    for name in ("sil_cut_at_T", "more_sil_tokens_than_frames", "segmented_before_too_short"):
         lp1, tk1 = z[name + "_lp"], z[name + "_tk"]
         C, anchors, tf, ign, simple, boost, enf = (int(v) for v in z[name + "_cfg"])
         lp, tk, T_len, S_len = cases.pad_batch([lp1], [tk1], C, C - 1)
