@@ -100,25 +100,22 @@ __device__ int detect_silence_w(const float *ps, int Tx, float thr, int k, int32
     const int nwin = (k > 1) ? (Tx - k + 1) : Tx;
     if (k > 1) {
         // cumsum[i], float64 accumulate (:508): 64 values per LDS round trip, handed from lane to lane with readlane
-        // so that no memory latency sits in the serial chain; lane j keeps cs[base + j]
-        double acc = 0.0;
+        // so that no memory latency sits in the serial chain.  Lane l adds the values j <= l of the slice (in order;
+        // adding 0.0 for the others changes nothing), so it ends with cumsum[base + l]; lane 63's sum carries over.
+        double carry = 0.0;
         for (int base = 0; base < Tx; base += 64) {
-            const float x = (base + lane < Tx) ? ps[base + lane] : 0.0f;
-            float mine = 0.0f;
-            const int nv = min(64, Tx - base);
-            if (nv == 64) {
+            const float x = (base + lane < Tx) ? ps[base + lane] : 0.0f; // (values past Tx add 0.0)
+            double acc = carry;
 #pragma unroll
-                for (int j = 0; j < 64; ++j) {
-                    acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
-                    mine = (lane == j) ? (float)acc : mine;
-                }
-            } else {
-                for (int j = 0; j < nv; ++j) {
-                    acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
-                    mine = (lane == j) ? (float)acc : mine;
-                }
+            for (int j = 0; j < 64; ++j) {
+                const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+                acc += (double)((lane >= j) ? xj : 0.0f);
             }
-            if (base + lane < Tx) cs[base + lane] = mine;
+            if (base + lane < Tx) cs[base + lane] = (float)acc;
+            const long long bits = __builtin_bit_cast(long long, acc);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 63);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), 63);
+            carry = __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
