@@ -283,9 +283,9 @@ def main():
 
 
 def ragged_main(args, dev, rank, world):
-    """Not the headline line: throughput and parity sample on a mixed-length shard (prints its own JSON)."""
+    """Not the headline line: throughput on a mixed-length shard (prints its own JSON; its parity check against the
+    oracle is tests/test_gpu_parity.py::test_mixed_length_shard_parity)."""
     from bournemouth_forced_aligner_amd import AlignmentUtils
-    from oracle import oracle as ora
     C, B = args.classes, args.batch
     lp, tk, T_len, S_len = synth_ragged(B, 200, 3000, C, 1004 + rank, dev)
     au = AlignmentUtils(blank_id=C - 1, silence_id=0)
@@ -300,15 +300,9 @@ def ragged_main(args, dev, rank, world):
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / args.steps
     frames = int(T_len.sum())
-    n = min(96, B)
-    exp = ora.decode_alignments(lp[:n].cpu().numpy(), tk[:n].cpu().numpy(), T_len[:n].numpy(), S_len[:n].numpy(),
-                                ora.make_params(C - 1, 0), seg_cap=res.segs.shape[1])
-    gs, gc = res.segs[:n].cpu().numpy(), res.seg_count[:n].cpu().numpy()
-    mism = sum(int(gc[b] != exp["seg_count"][b] or not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all()) for b in range(n))
     if rank == 0:
         print(json.dumps({"workload": f"ragged batch={B} T~U[200,3000] S=T//25 C={C}", "frames": frames,
                           "ms_per_step": el * 1e3, "frames_per_s": frames / el,
-                          "parity_sample": n, "parity_mismatching_utterances": mism,
                           "status_ok": bool((res.status.cpu() == 0).all())}))
 
 

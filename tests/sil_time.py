@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/sil_time.py -- step time of the silence-anchored (segmented) mode: headline shape with SIL at ~1/12 of the
+"""tests/sil_time.py -- step time of the silence-anchored (segmented) mode: headline shape with SIL at ~1/12 of the
 target positions and 12-40-frame planted silences (SURVEY.md section 8(d) "-sil" variant), parity sample included."""
 import os
 import sys

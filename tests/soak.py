@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/soak.py [n_batches] [seed] -- randomized differential soak of the HIP path against the CPU oracle
+"""tests/soak.py [n_batches] [seed] -- randomized differential soak of the HIP path against the CPU oracle
 (run on the GPU box).  Every batch draws its own head width, flags, length ranges and posterior sharpness;
 integer outputs must be identical.  Not part of pytest (minutes); prints one line per mismatch and a summary."""
 import os

@@ -240,7 +240,7 @@ def test_segmented_mode_with_pieces_beyond_1024_states(ora, gpu_device):
 
 
 def test_soak_regressions(ora, gpu_device):
-    """Cases the randomized soak (tools/soak.py) found: a silence segment whose SIL indices are spread over the whole
+    """Cases the randomized soak (tests/soak.py) found: a silence segment whose SIL indices are spread over the whole
     segment although the concatenation is cut off at T; one with more SIL tokens than frames (empty index ranges); T < S
     where the segmented attempt succeeds, so that the "audio too short" error of the standard mode never fires."""
     import os
@@ -271,6 +271,25 @@ def test_simple_mode_empty_target(ora, gpu_device):
         _compare(res, exp, T_len, check_mode=False)
         if not ign:
             assert exp["seg_count"][0] == 1 and exp["seg_count"][1] == 1 and exp["seg_count"][2] == 0
+
+
+def test_mixed_length_shard_parity(ora, gpu_device):
+    """bench.py --ragged's generator (T ~ U[200,3000], S = T // 25, per-utterance planted paths, reference-default
+    flags with the host class hint): every K1 class and layout in one batch, against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    C = 67
+    lp, tk, T_len, S_len = bench.synth_ragged(96, 200, 3000, C, 1004, gpu_device)
+    au = AlignmentUtils(blank_id=C - 1, silence_id=0)
+    hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=C)
+    res = au.decode_alignments_device(lp, tk, T_len.to(gpu_device), S_len.to(gpu_device), class_mask=hint)
+    torch.cuda.synchronize()
+    exp = ora.decode_alignments(lp.cpu().numpy(), tk.cpu().numpy(), T_len.numpy(), S_len.numpy(), ora.make_params(C - 1, 0),
+                                seg_cap=res.segs.shape[1])
+    _compare(res, exp, T_len.numpy())
 
 
 def test_confidences_parity(ora, gpu_device):
