@@ -23,7 +23,8 @@
  *   - calls are stream-ordered and return without synchronising; buffers must stay alive until
  *     the stream has been synchronised.  Inside a call the alignment kernels of different length
  *     classes may run side by side on streams owned by the handle; they are forked from and joined
- *     back into `stream` with events, so the ordering the caller sees is that of `stream` alone;
+ *     back into `stream` with events, so the ordering the caller sees is that of `stream` alone, and a call can be
+ *     stream-captured into a hipGraph (nothing in it synchronises or touches the host);
  *   - return value: BFA_OK or a negative bfa_status for call-level failures (bad argument,
  *     launch failure).  Per-utterance outcomes go to out_status[B] (see BFA_ITEM_*);
  *   - one handle per GPU per host thread; no hidden global state.

@@ -292,6 +292,42 @@ def test_mixed_length_shard_parity(ora, gpu_device):
     _compare(res, exp, T_len.numpy())
 
 
+def test_call_can_be_captured_into_a_graph(gpu_device):
+    """bfa_align_batch only enqueues work (kernels, a memset, event fork/join onto the handle's streams): with device
+    resident arguments the whole call can be stream-captured and replayed as a hipGraph."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    rng = np.random.default_rng(1)
+    lps, toks = [], []
+    for S, T in ((20, 300), (40, 700), (90, 1200), (10, 100), (120, 3000), (30, 500)):
+        lp, tk, _ = cases.planted_case(rng, T, S, C=67, blank=66, peak=8.0, sil_rate=0.1 if S == 30 else 0.0)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, 67, 66)
+    vd = AlignmentUtils(66, 0).viterbi_decoder
+    dev = gpu_device
+    lpd = torch.from_numpy(lp).to(dev)
+    tkd = torch.from_numpy(tk).to(dev).to(torch.int32)
+    Td = torch.from_numpy(np.asarray(T_len, np.int32)).to(dev)
+    Sd = torch.from_numpy(np.asarray(S_len, np.int32)).to(dev)
+    ref = vd.align_batch(lpd, tkd, Td, Sd, class_mask=None)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):   # warm-up on a side stream, as torch asks for before a capture
+        vd.align_batch(lpd, tkd, Td, Sd, class_mask=None)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        res = vd.align_batch(lpd, tkd, Td, Sd, class_mask=None)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert (res.status.cpu() == ref.status.cpu()).all()
+    assert (res.frame_phonemes.cpu() == ref.frame_phonemes.cpu()).all()
+    assert (res.frame_phonemes_idx.cpu() == ref.frame_phonemes_idx.cpu()).all()
+    assert (res.seg_count.cpu() == ref.seg_count.cpu()).all()
+
+
 def test_confidences_parity(ora, gpu_device):
     from bournemouth_forced_aligner_amd import calculate_confidences_batch
     rng = np.random.default_rng(9)
