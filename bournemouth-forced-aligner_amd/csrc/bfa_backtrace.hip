@@ -185,6 +185,101 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
     if (cg >= 1) walk_chunk(pre[1], cg - 1);
 }
 
+// Window layout with lane masks (WIN_SSTORE): [nrows] window bases (FPW frames per row), padded to 16 bytes, then per
+// frame R x {maskA, maskB}: bit l of maskA / maskB of slot r = A / B of state base[row] + l*R + r at that frame
+// (A = c0 < best, B = c1 < best; k = A ? (B ? 2 : 1) : 0).  Lane = frame: a lane keeps its frame's 2R masks in
+// registers (loaded three chunks ahead, coalesced), so a walk step is shift / and / ballot with no memory access.
+template <int R>
+__device__ __forceinline__ void walk_item_winmask(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
+{
+    constexpr int FPW = (R == 1) ? 16 : (R == 2) ? 8 : 4;
+    constexpr int FSH = (FPW == 16) ? 4 : (FPW == 8) ? 3 : 2;
+    constexpr int NPRE = 3;
+    constexpr int NQ = 2 * R; // 64-bit masks per frame
+    const DevParams &p = a.p;
+    const int b = it.utt;
+    int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
+    int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
+    const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
+    const int Ts = it.Ts;
+    const int nrows = (Ts + FPW - 1) >> FSH;
+    const uint32_t *bp_base = a.bp + it.bp_off;
+    const unsigned long long *masks = (const unsigned long long *)(bp_base + ((nrows + 3) & ~3));
+    const int inv_stride = 65536 / it.stride + 1; // (d * inv) >> 16 == d / stride for d < 1100, stride <= 4
+    int s = it.final_state;                       // wave-uniform walk state
+    const int nchunks = (Ts + 63) >> 6;
+
+    for (int j = lane; j < it.nt; j += 64) stok[j] = tok[j]; // see walk_item
+    wave_sync_lds();
+
+    unsigned long long pre[NPRE][NQ];
+    int preb[NPRE];
+    auto fetch = [&](unsigned long long (&dst)[NQ], int &dstb, int c) { // unconditional, clamped (see walk_item)
+        const int t = min(max(c, 0) * 64 + lane, Ts - 1);
+        const unsigned long long *src = masks + (int64_t)t * NQ;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dst[q] = src[q];
+        dstb = (int)bp_base[t >> FSH];
+    };
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) fetch(pre[k], preb[k], nchunks - 1 - k);
+
+    auto walk_chunk = [&](unsigned long long (&buf)[NQ], int &bufb, int c) {
+        const int t0 = c * 64;
+        const int n = min(Ts - t0, 64); // frames in this chunk
+        unsigned long long mk[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mk[q] = buf[q];
+        const int wbase = bufb;
+        fetch(buf, bufb, c - NPRE);
+        const int t = t0 + lane;
+        unsigned long long todo = (n == 64) ? ~0ull : ((1ull << n) - 1ull); // frames the walk has not passed
+        if (t0 == 0) todo &= ~1ull;                                          // frame 0 has no predecessor
+        int hi = n - 1;                                                      // lanes (.., hi] still unlabelled
+        int my_state = 0;
+        for (;;) {
+            // a frame at which s lies outside the window is below the next move: its code is not used
+            const int d = s - wbase;
+            const int dc = min(max(d, 0), 64 * R - 1);
+            const int xl = dc / R, xr = dc - xl * R;
+            unsigned long long mA = mk[0], mB = mk[1];
+#pragma unroll
+            for (int r = 1; r < R; ++r) { if (xr == r) { mA = mk[2 * r]; mB = mk[2 * r + 1]; } }
+            const bool inw = (unsigned)d < (unsigned)(64 * R);
+            const unsigned A = inw ? (unsigned)((mA >> xl) & 1ull) : 0u;
+            const unsigned long long mv = __ballot(A != 0u) & todo;
+            const int jl = (mv == 0ull) ? 0 : 63 - __builtin_clzll(mv); // latest frame at which the path moves
+            if (lane >= jl && lane <= hi) my_state = s;
+            if (mv == 0ull) break; // the path stays in s down to the chunk start
+            const unsigned B = (unsigned)((mB >> xl) & 1ull);
+            s -= 1 + (int)__builtin_amdgcn_readlane((int)B, jl); // k = A ? (B ? 2 : 1) : 0
+            hi = jl - 1;
+            todo &= (1ull << jl) - 1ull;
+        }
+        if (lane < n) {
+            const int o = t - it.pad_left; // :447-448 trim the boundary padding
+            if (o >= 0 && o < it.nout) {
+                int ph = p.blank, id = -1;
+                if (my_state >= 1) {
+                    const int q = ((my_state - 1) * inv_stride) >> 16;
+                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = stok[q]; id = it.tok0 + q; }
+                }
+                oph[it.out0 + o] = ph;
+                oid[it.out0 + o] = id;
+            }
+        }
+    };
+    static_assert(NPRE == 3, "the unrolled group below is written for three buffers");
+    int cg = nchunks - 1;
+    for (; cg >= NPRE - 1; cg -= NPRE) {
+        walk_chunk(pre[0], preb[0], cg);
+        walk_chunk(pre[1], preb[1], cg - 1);
+        walk_chunk(pre[2], preb[2], cg - 2);
+    }
+    if (cg >= 0) walk_chunk(pre[0], preb[0], cg);
+    if (cg >= 1) walk_chunk(pre[1], preb[1], cg - 1);
+}
+
 // Paths of more than 1024 states (k_dp_big): backpointers row-major, [frame][ng = ceil(L/16)] dwords, dword g =
 // states 16g..16g+15, 2 bits each.  Same ballot-jump walk; every lane keeps the dword of its frame for the current
 // state's group and reloads it when the walk enters another group (every <= 16 moves).
@@ -293,10 +388,10 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
         }
         if (it.win > 0) {
             switch (it.win) {
-            case 1: walk_item<1, true>(a, it, sbp, stok, lane); break;
-            case 2: walk_item<2, true>(a, it, sbp, stok, lane); break;
-            case 3: walk_item<3, true>(a, it, sbp, stok, lane); break;
-            default: walk_item<4, true>(a, it, sbp, stok, lane); break;
+            case 1: if (WIN_SSTORE) walk_item_winmask<1>(a, it, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
+            case 2: if (WIN_SSTORE) walk_item_winmask<2>(a, it, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
+            case 3: if (WIN_SSTORE) walk_item_winmask<3>(a, it, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
+            default: if (WIN_SSTORE) walk_item_winmask<4>(a, it, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
             }
         } else {
             switch (r_class_for_L(it.L)) {

@@ -80,8 +80,8 @@ Layout layout_for(int B, int Tmax, int Smax, const bfa_params *p)
     l.item_cap = B + (seg ? B * nseg_max : 0);
     const int R = bfa::r_class_for_L(Lmax);
     const int64_t quads = (Tmax + 3) / 4 + (seg ? 3 * (int64_t)(Smax / 2 + 2) : 0);
-    if (R > 0) l.bp_per_utt = quads * bfa::bp_words_for_R(R) * 64 + quads;
-    else l.bp_per_utt = quads * 4 * ((Lmax + 15) / 16);
+    if (R > 0) l.bp_per_utt = ((quads * bfa::bp_words_for_R(R) * 64 + quads + 4) + 3) & ~(int64_t)3; // 16-byte multiples
+    else l.bp_per_utt = ((quads * 4 * ((Lmax + 15) / 16) + 4) + 3) & ~(int64_t)3;
     return l;
 }
 

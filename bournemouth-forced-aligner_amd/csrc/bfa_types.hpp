@@ -129,6 +129,13 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // the full layout, which costs more than never trying): scores are sums of per-frame log-probabilities, so long
 // utterances cross it even with good posteriors.  Past WIN_MAX_FRAMES frames the planner does not try the window.
 constexpr int WIN_MAX_FRAMES = 1536;
+// Window backpointers as lane masks written by the scalar unit (1) or as per-lane packed dwords (0, kept for A/B):
+// with masks the consumer spends one v_cmp per code bit (the result lands in an SGPR pair and leaves through
+// s_store_dwordx4) instead of v_cmp + v_addc, and K2 reads its frame's masks straight from memory (no LDS staging).
+#ifndef BFA_WIN_SSTORE
+#define BFA_WIN_SSTORE 1
+#endif
+constexpr bool WIN_SSTORE = BFA_WIN_SSTORE != 0;
 __host__ __device__ inline int win_frames_per_word(int rw) { return rw == 1 ? 16 : (rw == 2 ? 8 : 4); }
 __host__ __device__ inline int win_class_for(int L, int bw, int Ts)
 {
