@@ -391,7 +391,9 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
             case 1: if (WIN_SSTORE) walk_item_winmask<1>(a, it, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
             case 2: if (WIN_SSTORE) walk_item_winmask<2>(a, it, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
             case 3: if (WIN_SSTORE) walk_item_winmask<3>(a, it, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
-            default: if (WIN_SSTORE) walk_item_winmask<4>(a, it, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
+            case 4: if (WIN_SSTORE) walk_item_winmask<4>(a, it, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
+            case 6: if (WIN_SSTORE) walk_item_winmask<6>(a, it, stok, lane); break;
+            default: if (WIN_SSTORE) walk_item_winmask<8>(a, it, stok, lane); break;
             }
         } else {
             switch (r_class_for_L(it.L)) {

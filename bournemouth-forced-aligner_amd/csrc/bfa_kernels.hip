@@ -385,11 +385,10 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
     unsigned wmask = 0;
     if (mode != 2 && (a.C == 67 || a.C == 17) && Lmax > 60) {
-        wmask = 15u; // Rw = 1..4; classes no utterance can use cost one empty launch each (narrow with the hint)
-        for (int rw = 4; rw >= 1; --rw) { // drop the classes above the one the longest possible path would take
-            const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
+        wmask = 0xafu; // Rw in {1,2,3,4,6,8} (bit Rw-1); classes no utterance can use cost one empty launch each
+        const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
+        for (int rw = 8; rw >= 1; --rw) // drop the classes above the one the longest possible path would take
             if (top > 0 && rw > top) wmask &= ~(1u << (rw - 1));
-        }
         if (p.class_mask) wmask &= (p.class_mask >> 8);
     }
     a.p.win_mask = wmask;

@@ -142,12 +142,16 @@ __host__ __device__ inline int win_class_for(int L, int bw, int Ts)
     if (bw <= 0 || Ts > WIN_MAX_FRAMES) return 0;
     const int rfull = r_class_for_L(L);
     if (rfull == 0) return 0;
-    for (int rw = 1; rw <= 4 && rw < rfull; ++rw)
+    constexpr int classes[6] = {1, 2, 3, 4, 6, 8}; // window states-per-lane classes
+    for (int k = 0; k < 6; ++k) {
+        const int rw = classes[k];
+        if (rw >= rfull) break;
         if (2 * bw + 1 + win_frames_per_word(rw) + 2 + rw + 1 <= 64 * rw) return rw;
+    }
     return 0;
 }
-// window class bits in the class mask: bit 8 + (Rw-1)
-__host__ __device__ inline unsigned win_class_bit(int rw) { return (rw >= 1 && rw <= 4) ? (1u << (7 + rw)) : 0u; }
+// window class bits in the class mask: bit 8 + (Rw-1), Rw in {1,2,3,4,6,8}
+__host__ __device__ inline unsigned win_class_bit(int rw) { return (rw >= 1 && rw <= 8) ? (1u << (7 + rw)) : 0u; }
 
 // all classes up to and including the class of L
 __host__ __device__ inline unsigned r_class_mask_upto(int L)

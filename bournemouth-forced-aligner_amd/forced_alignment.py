@@ -162,7 +162,7 @@ class ViterbiDecoder:
         if bw <= 0 or full is None or T > cls._WIN_MAX_FRAMES:
             return 0
         rfull = (2, 3, 4, 6, 8, 12, 16)[full]
-        for rw in (1, 2, 3, 4):
+        for rw in (1, 2, 3, 4, 6, 8):
             if rw >= rfull:
                 break
             frames_per_word = {1: 16, 2: 8}.get(rw, 4)
@@ -174,7 +174,7 @@ class ViterbiDecoder:
                         boost_targets=True, enforce_minimum=True):
         """Optional host-side hint for bfa_params.reserved[0]: the K1 kernel classes that occur in this batch,
         from HOST copies of the lengths.  Bits 0-6: full-layout states-per-lane classes {2,3,4,6,8,12,16};
-        bits 8-11: sliding-window classes Rw = 1..4 (used for standard-mode DPs whose band is narrower than
+        bits 8-15: sliding-window classes Rw in {1,2,3,4,6,8} at bit 7+Rw (used for standard-mode DPs whose band is narrower than
         the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`).
         `has_sil` says whether any target may contain the silence id (then the segmented mode can create
         shorter DPs, and every full class up to the largest is kept; otherwise bit 16 tells the library to
@@ -205,7 +205,7 @@ class ViterbiDecoder:
         if window_ok:                                            # bfa_types.hpp win_class_for
             bw = np.where(L > 60, np.maximum(L // 4, 20), 0)
             rfull = classes[np.minimum(ci, 6)]
-            for r in (4, 3, 2, 1):
+            for r in (8, 6, 4, 3, 2, 1):
                 fpw = {1: 16, 2: 8}.get(r, 4)
                 fits = (2 * bw + 1 + fpw + 2 + r + 1 <= 64 * r) & (r < rfull)
                 rw[fits] = r

@@ -84,7 +84,7 @@ typedef struct {
     int32_t max_blanks;      /* assort_frames(max_blanks=10) */
     int32_t reserved[3];     /* [0] : optional host hint (0 = derive everything from the tensor shapes):
                                 bits 0-6  K1 full-layout states-per-lane classes {2,3,4,6,8,12,16} worth launching,
-                                bits 8-11 K1 sliding-window classes Rw = 1..4 worth launching,
+                                bits 8-15 K1 sliding-window classes Rw in {1,2,3,4,6,8} (bit 7+Rw) worth launching,
                                 bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
                                           silence-anchored planning kernels are not launched */
 } bfa_params;

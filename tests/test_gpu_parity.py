@@ -87,8 +87,8 @@ def test_sliding_window_classes(ora, gpu_device, C):
     rng = np.random.default_rng(4200 + C)
     blank = C - 1
     lps, toks = [], []
-    for S in (15, 16, 20, 25, 26, 33, 40, 47, 48, 60, 63, 64, 90, 120, 121):   # L = 4S+1: window classes 1,2,3,4 and none
-        for T in (4 * S + 1, 4 * S + 2, 4 * S + 9, 5 * S + 3, 8 * S, 25 * S):
+    for S in (15, 16, 20, 25, 26, 33, 40, 47, 48, 60, 63, 64, 90, 120, 121, 150, 180, 187, 188, 220, 250):   # L = 4S+1: window classes 1,2,3,4,6,8 and none
+        for T in (4 * S + 1, 4 * S + 2, 4 * S + 9, 5 * S + 3, min(8 * S, 1536), 25 * S):
             for peak in (9.0, 3.0, 0.3):
                 lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=peak, sigma=1.0, repeat_rate=0.15)
                 lps.append(lp)

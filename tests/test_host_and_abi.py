@@ -111,6 +111,9 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=40) == NS | 0b1       # other widths: generic kernel
     assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
     assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001       # T > 1536: full layout
+    assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 13     # L=721, bw=180 -> 372 states -> Rw=6
+    assert vd.class_mask_hint([900], [187], has_sil=False, n_classes=67) == NS | 1 << 15     # L=749, bw=187 -> 390 states -> Rw=8
+    assert vd.class_mask_hint([1200], [250], has_sil=False, n_classes=67) == NS | 1 << 6     # L=1001, bw=250: 516 states > 512 -> full R=16
     assert vd.class_mask_hint([], [], has_sil=False) == 0
 
 
