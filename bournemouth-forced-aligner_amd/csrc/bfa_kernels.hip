@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
             it.kind = ITEM_DP;
             it.bw = band_standard(L);
             mode = BFA_MODE_STANDARD;
-            const int rw = win_class_for(L, it.bw, T); // band narrow enough (and the utterance short enough) for the window?
+            // band narrow enough, and the utterance short enough in frames and tokens, for the window?
+            const int rw = (S <= p.win_max_tokens) ? win_class_for(L, it.bw, T) : 0;
             if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
         }
         (void)fallback_short;

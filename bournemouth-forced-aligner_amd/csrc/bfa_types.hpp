@@ -46,6 +46,7 @@ struct DevParams {
     int32_t blank, sil, anchors, ignore_noise, truly_forced, boost, enforce, simple, max_blanks;
     uint32_t class_mask; // K1 classes to launch (host hint), 0 = derive from the shapes
     uint32_t win_mask;   // sliding-window classes the planner may use (bit Rw-1), set by bfa_launch_align
+    int32_t win_max_tokens; // no window attempt for utterances with more tokens
 };
 
 // everything the kernels of one bfa_align_batch call need; passed by value
@@ -129,6 +130,10 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // the full layout, which costs more than never trying): scores are sums of per-frame log-probabilities, so long
 // utterances cross it even with good posteriors.  Past WIN_MAX_FRAMES frames the planner does not try the window.
 constexpr int WIN_MAX_FRAMES = 1536;
+// ... and every token costs the path at least one frame in a blank state; with a model that does not put noise between
+// phonemes that is about -15 per token after the boost, so past ~64 tokens the -1000 line is usually crossed too.
+// bfa_params.reserved[1] > 0 overrides this limit (e.g. a large value for posteriors known to be CTC-like).
+constexpr int WIN_MAX_TOKENS = 64;
 // Window backpointers as lane masks written by the scalar unit (1) or as per-lane packed dwords (0, kept for A/B):
 // with masks the consumer spends one v_cmp per code bit (the result lands in an SGPR pair and leaves through
 // s_store_dwordx4) instead of v_cmp + v_addc, and K2 reads its frame's masks straight from memory (no LDS staging).

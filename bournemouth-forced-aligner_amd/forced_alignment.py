@@ -120,6 +120,9 @@ class ViterbiDecoder:
         self.truly_forced = truly_forced
         self._neg_inf = -1000.0
         self._ws = _Workspace()
+        # K1's sliding-window variant is only tried up to this many tokens (None = the library's 64); raise it for
+        # posteriors that are known to keep path scores above the -1000 sentinel (bfa_params.reserved[1])
+        self.window_max_tokens = None
 
     def set_blank_id(self, blank_id):
         """forced_alignment.py:25-27"""
@@ -152,6 +155,7 @@ class ViterbiDecoder:
         return None
 
     _WIN_MAX_FRAMES = 1536  # bfa_types.hpp WIN_MAX_FRAMES
+    _WIN_MAX_TOKENS = 64    # bfa_types.hpp WIN_MAX_TOKENS (bfa_params.reserved[1] / `window_max_tokens` overrides)
 
     @classmethod
     def _win_class(cls, L, T=0):
@@ -209,7 +213,8 @@ class ViterbiDecoder:
                 fpw = {1: 16, 2: 8}.get(r, 4)
                 fits = (2 * bw + 1 + fpw + 2 + r + 1 <= 64 * r) & (r < rfull)
                 rw[fits] = r
-            rw[(bw <= 0) | (T > self._WIN_MAX_FRAMES) | (ci > 6) | ~is_dp] = 0
+            max_tok = self.window_max_tokens if self.window_max_tokens else self._WIN_MAX_TOKENS
+            rw[(bw <= 0) | (T > self._WIN_MAX_FRAMES) | (S > max_tok) | (ci > 6) | ~is_dp] = 0
         for r in np.unique(rw[rw > 0]):
             mask |= 1 << (7 + int(r))                            # (the rare sentinel rerun needs no hint bit)
         for c in np.unique(ci[is_dp & (rw == 0) & (ci <= 6)]):
@@ -255,6 +260,7 @@ class ViterbiDecoder:
         T_len = _as_i32(pred_lens, dev)
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
         params.reserved[0] = int(class_mask)
+        params.reserved[1] = int(self.window_max_tokens or 0)
         if seg_cap is None:
             seg_cap = Smax + 2 if self.ignore_noise else Tmax + 1
         L = _lib.lib()

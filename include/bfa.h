@@ -86,7 +86,11 @@ typedef struct {
                                 bits 0-6  K1 full-layout states-per-lane classes {2,3,4,6,8,12,16} worth launching,
                                 bits 8-15 K1 sliding-window classes Rw in {1,2,3,4,6,8} (bit 7+Rw) worth launching,
                                 bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
-                                          silence-anchored planning kernels are not launched */
+                                          silence-anchored planning kernels are not launched
+                                [1] : window token limit, 0 = default (64).  K1's sliding-window variant is exact only while
+                                the path score stays above the reference's -1000 sentinel; otherwise the utterance is
+                                redone with the full state layout.  Every token costs the path a frame in a blank state,
+                                so utterances with more tokens than this are not tried in the window at all. */
 } bfa_params;
 
 /* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),

@@ -56,6 +56,7 @@ def main():
             lps.append(lp); toks.append(tk)
         lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
         au = AlignmentUtils(blank, 0, silence_anchors=anchors, ignore_noise=ign, truly_forced=tf)
+        au.viterbi_decoder.window_max_tokens = None if rng.integers(0, 2) else 4096
         hint = None if rng.integers(0, 2) else 0   # None: no hint at all; 0: derived by align_batch from the host lengths
         if rng.integers(0, 2):
             has_sil = bool((tk == 0).any())

@@ -23,10 +23,12 @@ def _mk_batch(rng, n, C, Tr, Sr, **kw):
     return cases.pad_batch(lps, toks, C, blank)
 
 
-def _run_both(ora, dev, lp, tk, T_len, S_len, C, anchors=10, ign=True, tf=True, boost=True, enf=True, simple=False):
+def _run_both(ora, dev, lp, tk, T_len, S_len, C, anchors=10, ign=True, tf=True, boost=True, enf=True, simple=False,
+              window_max_tokens=None):
     from bournemouth_forced_aligner_amd import AlignmentUtils
     blank = C - 1
     au = AlignmentUtils(blank, 0, silence_anchors=anchors, ignore_noise=ign, truly_forced=tf)
+    au.viterbi_decoder.window_max_tokens = window_max_tokens
     lpd = torch.from_numpy(lp).to(dev)
     res = au.viterbi_decoder.align_batch(lpd, torch.from_numpy(tk), T_len, S_len, boost_targets=boost,
                                          enforce_minimum=enf, anchor_pauses=anchors > 0, simple=simple,
@@ -96,8 +98,9 @@ def test_sliding_window_classes(ora, gpu_device, C):
     for lo in range(0, len(lps), 90):
         lp, tk, T_len, S_len = cases.pad_batch(lps[lo:lo + 90], toks[lo:lo + 90], C, blank)
         for tf in (True, False):
-            res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=0, tf=tf)
-            _compare(res, exp, T_len)
+            for cap in (None, 4096):   # the library's token limit for the window, and no limit (all six classes)
+                res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=0, tf=tf, window_max_tokens=cap)
+                _compare(res, exp, T_len)
 
 
 def test_sliding_window_equals_full_layout(gpu_device):
@@ -116,6 +119,7 @@ def test_sliding_window_equals_full_layout(gpu_device):
     lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
     au = AlignmentUtils(blank, 0, silence_anchors=0)
     vd = au.viterbi_decoder
+    vd.window_max_tokens = 4096
     h_win = vd.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=C)
     h_full = vd.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False)
     assert (h_win >> 8) & 15 and not ((h_full >> 8) & 15)

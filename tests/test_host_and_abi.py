@@ -105,10 +105,14 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([600], [20], has_sil=False) == NS | 0b1                     # L=81  -> R=2
     assert vd.class_mask_hint([1000], [40], has_sil=True) == 0b11                         # segments may be shorter
     assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False) == NS | 0b10001       # L=481 -> R=8, L=33 -> R=2
-    # sliding-window classes (bits 8-11) on the 67-class head: L=161, bw=40 -> Rw=2; L=81, bw=20 -> Rw=1
+    # sliding-window classes (bits 8-15) on the 67-class head: L=161, bw=40 -> Rw=2; L=81, bw=20 -> Rw=1
     assert vd.class_mask_hint([1000] * 4, [40] * 4, has_sil=False, n_classes=67) == NS | 1 << 9
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=67) == NS | 1 << 8
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=40) == NS | 0b1       # other widths: generic kernel
+    # more than 64 tokens: no window attempt (the path score would usually cross the sentinel) unless the limit is raised
+    assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001
+    assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 5      # R=12
+    vd.window_max_tokens = 4096
     assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
     assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001       # T > 1536: full layout
     assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 13     # L=721, bw=180 -> 372 states -> Rw=6
