@@ -185,31 +185,33 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
     if (cg >= 1) walk_chunk(pre[1], cg - 1);
 }
 
-// Window layout with lane masks (WIN_SSTORE): [nrows] window bases (FPW frames per row), padded to 16 bytes, then per
-// frame R x {maskA, maskB}: bit l of maskA / maskB of slot r = A / B of state base[row] + l*R + r at that frame
-// (A = c0 < best, B = c1 < best; k = A ? (B ? 2 : 1) : 0).  Lane = frame: a lane keeps its frame's 2R masks in
-// registers (loaded three chunks ahead, coalesced), so a walk step is shift / and / ballot with no memory access.
-template <int R>
-__device__ __forceinline__ void walk_item_winmask(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
+// Lane-mask layout of the window items (WIN_SSTORE): [nrows] window bases (FPW frames per row), padded to 16 bytes, then
+// per frame R x {maskA, maskB} (WIN = false would be the same masks without the header and with base 0).  Bit l
+// of maskA / maskB of slot r = A / B of state base + l*R + r at that frame (base = 0 without a window; A = c0 < best,
+// B = c1 < best; k = A ? (B ? 2 : 1) : 0).  Lane = frame: a lane keeps its frame's 2R masks in registers (loaded ahead,
+// coalesced), so a walk step is select / shift / ballot with no memory access.
+template <int R, bool WIN>
+__device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
 {
     constexpr int FPW = (R == 1) ? 16 : (R == 2) ? 8 : 4;
     constexpr int FSH = (FPW == 16) ? 4 : (FPW == 8) ? 3 : 2;
-    constexpr int NPRE = 3;
-    constexpr int NQ = 2 * R; // 64-bit masks per frame
+    constexpr int NPRE = (R <= 4) ? 3 : 1; // chunks in flight in registers (2R qwords per lane each)
+    constexpr int NQ = 2 * R;                              // 64-bit masks per frame
     const DevParams &p = a.p;
     const int b = it.utt;
     int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
     int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
     const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
-    const int Ts = it.Ts;
+    const int Ts = it.Ts, L = it.L;
     const int nrows = (Ts + FPW - 1) >> FSH;
     const uint32_t *bp_base = a.bp + it.bp_off;
-    const unsigned long long *masks = (const unsigned long long *)(bp_base + ((nrows + 3) & ~3));
+    const unsigned long long *masks = (const unsigned long long *)(bp_base + (WIN ? ((nrows + 3) & ~3) : 0));
     const int inv_stride = 65536 / it.stride + 1; // (d * inv) >> 16 == d / stride for d < 1100, stride <= 4
     int s = it.final_state;                       // wave-uniform walk state
     const int nchunks = (Ts + 63) >> 6;
 
-    for (int j = lane; j < it.nt; j += 64) stok[j] = tok[j]; // see walk_item
+    wave_sync_lds(); // the previous item's readers of stok are done
+    for (int j = lane; j < it.nt && j < 1024; j += 64) stok[j] = tok[j]; // see walk_item
     wave_sync_lds();
 
     unsigned long long pre[NPRE][NQ];
@@ -219,7 +221,7 @@ __device__ __forceinline__ void walk_item_winmask(const AlignArgs &a, const Item
         const unsigned long long *src = masks + (int64_t)t * NQ;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) dst[q] = src[q];
-        dstb = (int)bp_base[t >> FSH];
+        dstb = WIN ? (int)bp_base[t >> FSH] : 0;
     };
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) fetch(pre[k], preb[k], nchunks - 1 - k);
@@ -238,7 +240,7 @@ __device__ __forceinline__ void walk_item_winmask(const AlignArgs &a, const Item
         int hi = n - 1;                                                      // lanes (.., hi] still unlabelled
         int my_state = 0;
         for (;;) {
-            // a frame at which s lies outside the window is below the next move: its code is not used
+            // (window) a frame at which s lies outside the window is below the next move: its code is not used
             const int d = s - wbase;
             const int dc = min(max(d, 0), 64 * R - 1);
             const int xl = dc / R, xr = dc - xl * R;
@@ -253,6 +255,7 @@ __device__ __forceinline__ void walk_item_winmask(const AlignArgs &a, const Item
             if (mv == 0ull) break; // the path stays in s down to the chunk start
             const unsigned B = (unsigned)((mB >> xl) & 1ull);
             s -= 1 + (int)__builtin_amdgcn_readlane((int)B, jl); // k = A ? (B ? 2 : 1) : 0
+            if (!WIN && s < 0) s += L;                           // python negative-index wrap (:692)
             hi = jl - 1;
             todo &= (1ull << jl) - 1ull;
         }
@@ -262,22 +265,31 @@ __device__ __forceinline__ void walk_item_winmask(const AlignArgs &a, const Item
                 int ph = p.blank, id = -1;
                 if (my_state >= 1) {
                     const int q = ((my_state - 1) * inv_stride) >> 16;
-                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = stok[q]; id = it.tok0 + q; }
+                    if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = (q < 1024) ? stok[q] : tok[q]; id = it.tok0 + q; }
                 }
                 oph[it.out0 + o] = ph;
                 oid[it.out0 + o] = id;
             }
         }
     };
-    static_assert(NPRE == 3, "the unrolled group below is written for three buffers");
     int cg = nchunks - 1;
-    for (; cg >= NPRE - 1; cg -= NPRE) {
-        walk_chunk(pre[0], preb[0], cg);
-        walk_chunk(pre[1], preb[1], cg - 1);
-        walk_chunk(pre[2], preb[2], cg - 2);
+    if (NPRE == 3) {
+        for (; cg >= 2; cg -= 3) { // no branches around the chunks of a group (see walk_item's fetch)
+            walk_chunk(pre[0], preb[0], cg);
+            walk_chunk(pre[NPRE > 1 ? 1 : 0], preb[NPRE > 1 ? 1 : 0], cg - 1);
+            walk_chunk(pre[NPRE > 2 ? 2 : 0], preb[NPRE > 2 ? 2 : 0], cg - 2);
+        }
+        if (cg >= 0) walk_chunk(pre[0], preb[0], cg);
+        if (cg >= 1) walk_chunk(pre[NPRE > 1 ? 1 : 0], preb[NPRE > 1 ? 1 : 0], cg - 1);
+    } else if (NPRE == 2) {
+        for (; cg >= 1; cg -= 2) {
+            walk_chunk(pre[0], preb[0], cg);
+            walk_chunk(pre[NPRE > 1 ? 1 : 0], preb[NPRE > 1 ? 1 : 0], cg - 1);
+        }
+        if (cg >= 0) walk_chunk(pre[0], preb[0], cg);
+    } else {
+        for (; cg >= 0; --cg) walk_chunk(pre[0], preb[0], cg);
     }
-    if (cg >= 0) walk_chunk(pre[0], preb[0], cg);
-    if (cg >= 1) walk_chunk(pre[1], preb[1], cg - 1);
 }
 
 // Paths of more than 1024 states (k_dp_big): backpointers row-major, [frame][ng = ceil(L/16)] dwords, dword g =
@@ -336,7 +348,8 @@ __device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it
     (void)stok;
 }
 
-__global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
+// (4 waves per SIMD: a 4096-utterance batch is resident at once)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_backtrace(AlignArgs a)
 {
     __shared__ uint32_t sbp[16 * 64]; // one chunk: <= 1024 dwords
     __shared__ int32_t stok[1024];    // the item's tokens (nt <= L <= 1024)
@@ -388,12 +401,12 @@ __global__ __launch_bounds__(64) void k_backtrace(AlignArgs a)
         }
         if (it.win > 0) {
             switch (it.win) {
-            case 1: if (WIN_SSTORE) walk_item_winmask<1>(a, it, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
-            case 2: if (WIN_SSTORE) walk_item_winmask<2>(a, it, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
-            case 3: if (WIN_SSTORE) walk_item_winmask<3>(a, it, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
-            case 4: if (WIN_SSTORE) walk_item_winmask<4>(a, it, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
-            case 6: if (WIN_SSTORE) walk_item_winmask<6>(a, it, stok, lane); break;
-            default: if (WIN_SSTORE) walk_item_winmask<8>(a, it, stok, lane); break;
+            case 1: if (WIN_SSTORE) walk_item_mask<1, true>(a, it, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
+            case 2: if (WIN_SSTORE) walk_item_mask<2, true>(a, it, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
+            case 3: if (WIN_SSTORE) walk_item_mask<3, true>(a, it, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
+            case 4: if (WIN_SSTORE) walk_item_mask<4, true>(a, it, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
+            case 6: if (WIN_SSTORE) walk_item_mask<6, true>(a, it, stok, lane); break;
+            default: if (WIN_SSTORE) walk_item_mask<8, true>(a, it, stok, lane); break;
             }
         } else {
             switch (r_class_for_L(it.L)) {
