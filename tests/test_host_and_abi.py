@@ -197,3 +197,20 @@ def test_textgrid_writer_matches_the_reference_examples():
     assert dict_to_textgrid({"segments": [{"start": 0.0, "end": 2.5}]}) == exp["empty"]
     with pytest.raises(ValueError):
         dict_to_textgrid({"segments": []})
+
+
+def test_backtrace_kernel_keeps_four_waves_per_simd():
+    """A 4096-utterance batch is only resident at once in K2 if the kernel fits 4 waves per SIMD (<= 128 VGPRs); every
+    new per-layout instantiation of the walk counts against that (the compiler's resource remark is the check)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bournemouth-forced-aligner_amd", "csrc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                          "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", "-c",
+                          os.path.join(csrc, "bfa_backtrace.hip"), "-o", os.devnull],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    occ = [int(m) for m in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", out.stderr)]
+    assert occ and min(occ) >= 4, out.stderr[-1500:]
