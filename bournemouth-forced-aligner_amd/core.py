@@ -12,6 +12,7 @@ this package: they are injected as callables and stay on PyTorch-ROCm / the host
 import numpy as np
 import torch
 
+from .coverage import ensure_target_coverage
 from .forced_alignment import AlignmentUtils
 from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
 
@@ -22,8 +23,6 @@ class PhonemeTimestampAligner:
                  boost_targets=True, enforce_minimum=True, enforce_all_targets=True, ensure_completeness=False,
                  ignore_noise=True, extend_soft_boundaries=True, boundary_softness=3, sample_rate=16000,
                  phoneme_id_to_label=None, group_id_to_label=None):
-        if ensure_completeness:
-            raise NotImplementedError("ensure_completeness=True (core.py:516-657) is outside the accelerated path")
         self.posterior_fn = posterior_fn
         self.phonemizer = phonemizer
         self.phoneme_id_to_group_id = phoneme_id_to_group_id
@@ -61,10 +60,27 @@ class PhonemeTimestampAligner:
     def _head(self, utils, log_probs, seqs, seq_lens, spectral_lens):
         res = utils.decode_alignments_device(log_probs, seqs, spectral_lens, seq_lens,
                                              boost_targets=self.boost_targets, enforce_minimum=self.enforce_minimum)
+        estimated = None
+        if self.ensure_completeness:
+            # rare-case repair over a handful of rows per utterance: host side (coverage.py), between the device
+            # alignment and the device soft-boundary / confidence passes.  The completed rows are valid and sorted,
+            # so the device coverage stage of bfa_postprocess leaves them as they are.
+            res.raise_for_status()
+            rows = ensure_target_coverage(seqs, res.to_lists(), seq_lens, utils.viterbi_decoder.silence_id)
+            cap = res.segs.shape[1]
+            host = np.zeros((len(rows), cap, 4), np.int32)
+            for b, rs in enumerate(rows):
+                if len(rs) > cap:
+                    raise RuntimeError(f"item {b}: {len(rs)} completed rows exceed seg_cap {cap}")
+                if rs:
+                    host[b, :len(rs)] = [r[:4] for r in rs]
+            res.segs.copy_(torch.from_numpy(host))
+            res.seg_count.copy_(torch.tensor([len(rs) for rs in rows], dtype=torch.int32))
+            estimated = [[bool(r[4]) for r in rs] for rs in rows]
         postprocess_batch(log_probs, seq_lens, res.segs, res.seg_count, extend=self.extend_soft_boundaries,
                           boundary_softness=self.boundary_softness)
         conf, cstat = calculate_confidences_batch(log_probs, res.segs, res.seg_count)  # padded rows (core.py:936)
-        return res, conf, cstat
+        return res, conf, cstat, estimated
 
     def extract_timestamps_from_logits(self, logits_class, logits_group, spectral_lens, phoneme_sequences, wav_lens,
                                        start_offset_times=0, group_sequences=None, do_groups=True):
@@ -101,7 +117,7 @@ class PhonemeTimestampAligner:
         pending = []
         for key, utils, lp, seqs in heads:
             pending.append((key, self._head(utils, lp, seqs, ph_seq_lens, spec)))
-        for key, (res, conf, cstat) in pending:
+        for key, (res, conf, cstat, estimated) in pending:
             res.raise_for_status()
             if int((cstat.cpu() != 0).sum()) != 0:
                 raise IndexError("confidence pass: phoneme id or start frame out of range")
@@ -109,8 +125,8 @@ class PhonemeTimestampAligner:
             segs = res.segs.cpu().numpy()
             cf = conf.cpu().numpy()
             for b in range(B):
-                rows = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), False, float(cf[b, i]))
-                        for i, r in enumerate(segs[b, :cnt[b]])]
+                rows = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), estimated[b][i] if estimated else False,
+                         float(cf[b, i])) for i, r in enumerate(segs[b, :cnt[b]])]
                 off = start_offset_times[b] if isinstance(start_offset_times, (list, tuple)) else start_offset_times
                 rows = convert_to_ms(rows, torch.tensor(spec[b]), off, wav_lens[b], self.resampler_sample_rate)
                 out[b][key] = sorted(rows, key=lambda x: x[6])  # core.py:955-956
@@ -130,12 +146,173 @@ class PhonemeTimestampAligner:
         n = len(ts)
         return ts, [None] * n, [None] * n
 
+    def extract_timestamps_from_logits_simplified(self, logits_class, spectral_lens, phoneme_sequences, wav_lens,
+                                                  start_offset_times=0.0):
+        """core.py:1018-1044 given the model's logits: log_softmax -> decode_alignments_simple -> ms.  No boost,
+        floor, anchoring, coverage or confidence stage; rows are (id, start_frame, end_frame, target_seq_idx, False,
+        0.0, start_ms, end_ms) as convert_to_ms pads 4-tuples (utils.py:133-138), ms in float64 because
+        `spectral_lens[b]` is a plain int there."""
+        dev = self.device
+        B = logits_class.shape[0]
+        if isinstance(phoneme_sequences, torch.Tensor):
+            ph_seq_lens = [int((row != self.blank_class).sum()) for row in phoneme_sequences]  # core.py:1004-1005
+            ph = phoneme_sequences.to(torch.int32)
+        else:
+            ph_seq_lens = [len(s) for s in phoneme_sequences]
+            ph = torch.full((B, max(1, max(ph_seq_lens))), self.blank_class, dtype=torch.int32)
+            for b, s in enumerate(phoneme_sequences):
+                ph[b, :len(s)] = torch.as_tensor(list(s), dtype=torch.int32)
+        spec = [int(x) for x in spectral_lens]
+        lp = log_softmax(logits_class.to(dev))
+        rows = self.alignment_utils_p.decode_alignments_simple(lp, ph, spec, ph_seq_lens)
+        out = []
+        for b in range(B):
+            off = start_offset_times[b] if isinstance(start_offset_times, (list, tuple)) else start_offset_times
+            out.append({"phoneme_timestamps": convert_to_ms(rows[b], spec[b], off, wav_lens[b],
+                                                            self.resampler_sample_rate)})
+        return out
+
+    def extract_timestamps_from_segment_simplified(self, wavs, wav_lens, phoneme_sequences, start_offset_times=0.0,
+                                                   debug=True):
+        """core.py:995-1044."""
+        if self.posterior_fn is None:
+            raise AssertionError("CUPE extractor model is not loaded: pass posterior_fn=...")
+        logits_class, _, spectral_lens = self.posterior_fn(wavs, wav_lens)
+        return self.extract_timestamps_from_logits_simplified(logits_class, spectral_lens, phoneme_sequences, wav_lens,
+                                                              start_offset_times)
+
+    # ---- host-side result shaping (core.py:1062-1210, 1620-1631, 1701-1733, 1780-1919)
+    def _align_words(self, phoneme_ts, word_num, words_list):
+        """core.py:1062-1120: group consecutive 'phoneme_ts' entries by their word number.  Quirks kept: entries
+        are paired with `word_num` by POSITION (not by target_seq_idx), only the first min(len) positions are
+        looked at, and a word is closed when the number changes or at the last position of `word_num` -- so a
+        final one-phoneme word that starts exactly there is never emitted, and nothing is closed at all when
+        `phoneme_ts` is the shorter list."""
+        if not phoneme_ts or not word_num:
+            return []
+        words_ts = []
+        last = len(word_num) - 1
+        cur, members, start_ms = word_num[0], [], phoneme_ts[0]["start_ms"]
+        for i in range(min(len(word_num), len(phoneme_ts))):
+            if word_num[i] == cur and i != last:
+                members.append(phoneme_ts[i])
+                continue
+            if word_num[i] == cur:  # the last position, still inside the current word
+                members.append(phoneme_ts[i])
+            words_ts.append({
+                "word": words_list[cur] if cur < len(words_list) else f"UNK_WORD_{cur}",
+                "start_ms": start_ms,
+                "end_ms": members[-1]["end_ms"],
+                "confidence": sum(m["confidence"] for m in members) / len(members),
+                "ph66": [m["phoneme_id"] for m in members],
+                "ipa": [m["ipa_label"] for m in members],
+            })
+            if i < last:
+                cur, members, start_ms = word_num[i], [phoneme_ts[i]], phoneme_ts[i]["start_ms"]
+        return words_ts
+
+    def analyze_alignment_coverage(self, target_sequence, aligned_timestamps, index_to_label):
+        """core.py:1701-1733: set-level coverage of the target ids by the aligned ids."""
+        target = set(target_sequence.tolist() if hasattr(target_sequence, "tolist") else target_sequence)
+        aligned = {row[0] for row in aligned_timestamps}
+        missing, extra = target - aligned, aligned - target
+        ratio = len(target - missing) / len(target) if target else 1.0
+        label = lambda p: index_to_label.get(p, f"UNK_{p}")
+        return {"target_count": len(target), "aligned_count": len(aligned), "missing_count": len(missing),
+                "extra_count": len(extra), "coverage_ratio": ratio, "missing_phonemes": [label(p) for p in missing],
+                "extra_phonemes": [label(p) for p in extra], "bad_alignment": ratio < 0.8}
+
+    def convert_to_textgrid(self, timestamps_dict, output_file=None, include_confidence=False):
+        """core.py:1620-1631."""
+        from .textgrid import dict_to_textgrid
+        text = dict_to_textgrid(timestamps_dict, output_file=None, include_confidence=include_confidence)
+        if output_file and text is not None:
+            with open(output_file, "w", encoding="utf-8") as f:
+                f.write(text)
+        return text
+
+    def ceil(self, float_value):
+        """core.py:1780-1781 (also for negative values: truncation towards zero plus one if there is a fraction)."""
+        return int(float_value) + (float_value % 1 > 0)
+
+    def compress_frames(self, frames_list):
+        """core.py:1783-1803: run-length pairs (value, count)."""
+        runs = []
+        for v in frames_list:
+            if runs and runs[-1][0] == v:
+                runs[-1][1] += 1
+            else:
+                runs.append([v, 1])
+        return [(v, n) for v, n in runs]
+
+    def decompress_frames(self, compressed_frames):
+        """core.py:1806-1811."""
+        return [v for v, n in compressed_frames for _ in range(n)]
+
+    def framewise_assortment(self, aligned_ts, total_frames, frames_per_second, gap_contraction=5,
+                             select_key="phoneme_id", offset_ms=0):
+        """core.py:1813-1919: one label per frame of a `frames_per_second` grid (for TTS consumers) from a list of
+        'phoneme_ts' / 'group_ts' / 'words_ts' entries.  Sorts `aligned_ts` in place by start_ms like the
+        reference.  Stage 1: each entry claims the still-unlabelled frames of [start-1, end+1) (first come, first
+        served in start order).  Stage 2, per unlabelled run that has a labelled frame on its left and either a
+        labelled frame on its right or the end of the grid: runs up to `gap_contraction` take the left label, runs
+        up to twice that are split at the midpoint, longer runs get `gap_contraction` frames from each side; the
+        rest stays -1.  A run ending at the grid's end has no right label: its right part stays -1."""
+        GAP = -1
+        ms_per_frame = 1000.0 / frames_per_second
+        aligned_ts.sort(key=lambda x: x["start_ms"])
+        labels = [GAP] * total_frames
+        for item in aligned_ts:
+            first = max(int((item["start_ms"] - offset_ms) / ms_per_frame), 0)
+            end = min(self.ceil((item["end_ms"] - offset_ms) / ms_per_frame), total_frames)
+            if end - first > total_frames:
+                continue
+            if select_key not in item:
+                raise ValueError(f"select_key '{select_key}' not found in timestamp item", item)
+            for f in range(max(first - 1, 0), min(end + 1, total_frames)):
+                if labels[f] == GAP:
+                    labels[f] = item[select_key]
+        gaps, f = [], 0
+        while f < total_frames:  # the unlabelled runs as they are BEFORE any of them is filled
+            if labels[f] != GAP:
+                f += 1
+                continue
+            g0 = f
+            while f < total_frames and labels[f] == GAP:
+                f += 1
+            gaps.append((g0, f))
+        for g0, g1 in gaps:
+            if g0 == 0:
+                continue
+            left = labels[g0 - 1]
+            at_end = g1 == total_frames
+            right = GAP if at_end else labels[g1]
+            if left == GAP or (right == GAP and not at_end):
+                continue
+            n = g1 - g0
+            if n <= gap_contraction:
+                labels[g0:g1] = [left] * n
+            elif n <= 2 * gap_contraction:
+                mid = g0 + n // 2
+                labels[g0:mid] = [left] * (mid - g0)
+                labels[mid:g1] = [right] * (g1 - mid)
+            else:
+                k = max(gap_contraction, 0)
+                labels[g0:g0 + k] = [left] * k
+                labels[g1 - k:g1] = [right] * k
+        return labels
+
     # ---- thin wrappers (core.py:1212, 1553, 1586)
-    def _post_process_segment(self, segment, ts, phoneme_timestamps, group_timestamps=None):
-        """core.py:1140-1210 (fields of 'phoneme_ts' / 'group_ts'; word alignment and coverage analysis are host
-        text utilities outside this package)."""
+    def _post_process_segment(self, segment, ts, phoneme_timestamps, group_timestamps=None, phoneme_sequence=None):
+        """core.py:1140-1210."""
         out = dict(segment)
+        if phoneme_sequence is None:
+            phoneme_sequence = ts.get("ph66", [])
+        out["coverage_analysis"] = self.analyze_alignment_coverage(phoneme_sequence, phoneme_timestamps,
+                                                                   self.phoneme_id_to_label)
         out["ipa"] = ts.get("eipa", "")
+        out["word_num"] = ts.get("word_num", "")
+        out["words"] = ts.get("words", "")
         out["phoneme_ts"] = [
             {"phoneme_id": int(p), "phoneme_label": self.phoneme_id_to_label.get(p, f"UNK_{p}"),
              "ipa_label": out["ipa"][tidx] if 0 <= tidx < len(out["ipa"]) else "overflow",
@@ -148,7 +325,13 @@ class PhonemeTimestampAligner:
                  "end_ms": float(ems), "confidence": float(c), "is_estimated": bool(est), "target_seq_idx": int(tidx),
                  "index": i}
                 for i, (g, sf, ef, tidx, est, c, sms, ems) in enumerate(group_timestamps)]
+        out["words_ts"] = self._align_words(out["phoneme_ts"], ts.get("word_num", []), ts.get("words", []))
         return out
+
+    def post_process_segment(self, segment, ts, phoneme_sequence, phoneme_timestamps, group_timestamps=None,
+                             debug=False):
+        """core.py:1140 (the reference's argument order)."""
+        return self._post_process_segment(segment, ts, phoneme_timestamps, group_timestamps, phoneme_sequence)
 
     def process_segments(self, srt_data, audio_wavs, extract_embeddings=False, do_groups=False, batch_size=16,
                          debug=False):

@@ -82,6 +82,58 @@ def test_level2_pipeline_against_reference(gold, gpu_device):
             np.testing.assert_array_equal(got_f[:, 1:], gf[:, 1:])
 
 
+def test_simplified_pipeline_against_reference(gold, gpu_device):
+    """extract_timestamps_from_segment_simplified (core.py:995-1044): log_softmax -> decode_alignments_simple ->
+    convert_to_ms with a plain-int spectral length (float64 ms); expected rows from the reference itself
+    (tests/golden/make_golden_host.py)."""
+    import json
+    from bournemouth_forced_aligner_amd import PhonemeTimestampAligner
+    exp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_cases.json")))["simplified"]
+    lc = torch.from_numpy(gold["l2_logits_class"])
+    spec = gold["l2_spectral_lens"].tolist()
+    B = lc.shape[0]
+    seqs = [gold["l2_tokens"][b, :gold["l2_seq_lens"][b]].tolist() for b in range(B)]
+    al = PhonemeTimestampAligner(posterior_fn=lambda w, wl: (lc, None, spec), device="cuda:0")
+    ts = al.extract_timestamps_from_segment_simplified(torch.zeros(B, 16), gold["l2_wav_lens"].tolist(), seqs,
+                                                       start_offset_times=[0.5 * b for b in range(B)], debug=False)
+    for b in range(B):
+        got = [[int(r[0]), int(r[1]), int(r[2]), int(r[3]), bool(r[4]), float(r[5]), float(r[6]), float(r[7])]
+               for r in ts[b]["phoneme_timestamps"]]
+        assert got == exp[b], f"item {b}"
+    # tensor input: lengths are the counts of non-blank entries (core.py:1004-1005)
+    tk = torch.from_numpy(gold["l2_tokens"].astype(np.int64))
+    ts2 = al.extract_timestamps_from_segment_simplified(torch.zeros(B, 16), gold["l2_wav_lens"].tolist(), tk,
+                                                        start_offset_times=[0.5 * b for b in range(B)], debug=False)
+    assert [t["phoneme_timestamps"] for t in ts2] == [t["phoneme_timestamps"] for t in ts]
+
+
+def test_level2_pipeline_with_completeness_against_reference(gpu_device):
+    """ensure_completeness=True (core.py:516-657): stride-1 utterances whose best path skips targets; the missing
+    targets come back as estimated rows, which then go through the soft-boundary and confidence passes."""
+    from bournemouth_forced_aligner_amd import PhonemeTimestampAligner
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "l2_complete.npz"))
+    lc, lg = torch.from_numpy(z["logits_class"]), torch.from_numpy(z["logits_group"])
+    spec = z["spectral_lens"].tolist()
+    B = lc.shape[0]
+    seqs = [z["tokens"][b, :z["seq_lens"][b]].tolist() for b in range(B)]
+    groups = [z["group_tokens"][b, :z["seq_lens"][b]].tolist() for b in range(B)]
+    al = PhonemeTimestampAligner(posterior_fn=lambda w, wl: (lc, lg, spec), device="cuda:0", ensure_completeness=True)
+    ts, _, _ = al.extract_timestamps_from_segment_batch(torch.zeros(B, 16), z["wav_lens"].tolist(), seqs,
+                                                        start_offset_times=0.25, group_sequences=groups, do_groups=True)
+    n_est = 0
+    for b in range(B):
+        for key, short in (("phoneme_timestamps", "p"), ("group_timestamps", "g")):
+            rows = ts[b][key]
+            gi, gf = z[f"{short}{b}_int"], z[f"{short}{b}_flt"]
+            got_i = np.array([[r[0], r[1], r[2], r[3], int(r[4])] for r in rows], np.int32).reshape(-1, 5)
+            np.testing.assert_array_equal(got_i, gi, err_msg=f"{key} item {b}")
+            got_f = np.array([[r[5], r[6], r[7]] for r in rows], np.float32).reshape(-1, 3)
+            np.testing.assert_allclose(got_f[:, 0], gf[:, 0], atol=2e-7, rtol=0)
+            np.testing.assert_array_equal(got_f[:, 1:], gf[:, 1:])
+            n_est += int(got_i[:, 4].sum())
+    assert n_est > 50
+
+
 def test_process_sentence_plumbing(gpu_device):
     """Config C1 ('butterfly'): 75 frames, ph66 targets [29,10,58,9,43,56,23] through process_sentence with an
     injected posterior model and phonemiser -- the structure of the reference's result dict (core.py:1166-1179)."""

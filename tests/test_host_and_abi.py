@@ -214,3 +214,90 @@ def test_backtrace_kernel_keeps_four_waves_per_simd():
     assert out.returncode == 0, out.stderr[-2000:]
     occ = [int(m) for m in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", out.stderr)]
     assert occ and min(occ) >= 4, out.stderr[-1500:]
+
+
+# ---- host-side result shaping against the reference's outputs (tests/golden/host_cases.json) ----
+@pytest.fixture(scope="module")
+def host_gold():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_cases.json")))
+
+
+def _host_aligner(**kw):
+    from bournemouth_forced_aligner_amd import PhonemeTimestampAligner
+    return PhonemeTimestampAligner(device="cpu", **kw)  # no GPU work is started by these helpers
+
+
+def test_align_words_matches_reference(host_gold):
+    import copy
+    al = _host_aligner()
+    for c in host_gold["words"]:
+        assert al._align_words(copy.deepcopy(c["phoneme_ts"]), c["word_num"], c["words"]) == c["expected"]
+
+
+def test_coverage_analysis_and_frame_runs_match_reference(host_gold):
+    al = _host_aligner()
+    labels = {i: f"L{i}" for i in range(0, 66, 2)}
+    for c in host_gold["coverage"]:
+        tgt = torch.tensor(c["target"]) if c["tensor"] else c["target"]
+        got = al.analyze_alignment_coverage(tgt, [tuple(r) for r in c["aligned"]], labels)
+        got["missing_phonemes"], got["extra_phonemes"] = sorted(got["missing_phonemes"]), sorted(got["extra_phonemes"])
+        assert got == c["expected"]
+    for c in host_gold["compress"]:
+        runs = al.compress_frames(c["frames"])
+        assert [list(r) for r in runs] == c["expected"]
+        assert al.decompress_frames(runs) == c["frames"]
+    assert al.compress_frames([]) == []
+    assert [al.ceil(x) for x in (2.0, 2.25, -2.5, -3.0, 0.0)] == [2, 3, -1, -3, 0]
+
+
+def test_framewise_assortment_matches_reference(host_gold):
+    import copy
+    al = _host_aligner()
+    for i, c in enumerate(host_gold["framewise"]):
+        ts = copy.deepcopy(c["ts"])
+        got = al.framewise_assortment(ts, c["total_frames"], c["fps"], gap_contraction=c["gap_contraction"],
+                                      select_key=c["key"], offset_ms=c["offset_ms"])
+        assert got == c["expected"], f"case {i}"
+        assert [t["start_ms"] for t in ts] == sorted(t["start_ms"] for t in c["ts"])  # sorted in place
+    with pytest.raises(ValueError):
+        al.framewise_assortment([{"start_ms": 0.0, "end_ms": 10.0}], 10, 100.0)
+
+
+def test_post_process_segment_matches_reference(host_gold):
+    al = _host_aligner(phoneme_id_to_label={i: f"P{i}" for i in range(60)}, group_id_to_label={i: f"G{i}" for i in range(14)})
+    for c in host_gold["post"]:
+        got = al.post_process_segment(dict(c["segment"]), dict(c["ts"]), torch.tensor(c["seq"]),
+                                      [tuple(r) for r in c["rows"]],
+                                      [tuple(r) for r in c["grows"]] if c["grows"] is not None else None)
+        ca = got["coverage_analysis"]
+        ca["missing_phonemes"], ca["extra_phonemes"] = sorted(ca["missing_phonemes"]), sorted(ca["extra_phonemes"])
+        assert got == c["expected"]
+
+
+def test_convert_to_textgrid_method(tmp_path):
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textgrid")
+    d = json.load(open(os.path.join(here, "LJ001-0002.vs.json")))
+    al = _host_aligner()
+    out = tmp_path / "x.TextGrid"
+    text = al.convert_to_textgrid(d, output_file=str(out))
+    assert text == open(os.path.join(here, "LJ001-0002.TextGrid"), encoding="utf-8").read()
+    assert out.read_text(encoding="utf-8") == text
+
+
+def test_complete_target_coverage_matches_reference(host_gold):
+    """ensure_target_coverage with ensure_completeness=True (core.py:462-679): 300 synthetic aligner outputs with
+    missing / repeated / invalid targets and trailing silences, expected rows from the reference."""
+    from bournemouth_forced_aligner_amd.coverage import ensure_target_coverage
+    n_est = 0
+    for i, c in enumerate(host_gold["complete"]):
+        rows = [tuple(r) for r in c["rows"]]
+        if c["expected"] == "raises":
+            with pytest.raises(Exception):
+                ensure_target_coverage([c["seq"]], [rows], seq_lens=[c["len"]], silence_class=c["sil"])
+            continue
+        got = ensure_target_coverage([torch.tensor(c["seq"])], [rows], seq_lens=[c["len"]], silence_class=c["sil"])[0]
+        assert [list(r) for r in got] == c["expected"], f"case {i}"
+        n_est += sum(1 for r in got if r[4])
+    assert n_est > 500
