@@ -9,12 +9,28 @@ this package: they are injected as callables and stay on PyTorch-ROCm / the host
     posterior_fn(wavs, wav_lens) -> (logits_class [B,T,C_p], logits_group [B,T,C_g], spectral_lens list[int])
     phonemizer(text)             -> dict(ph66=[ids], pg16=[group ids] (optional), words/word_num/eipa (optional))
 """
+import itertools
+
 import numpy as np
 import torch
 
 from .coverage import ensure_target_coverage
 from .forced_alignment import AlignmentUtils
 from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
+
+
+def _pad_rows(rows, fill):
+    """list of id lists -> int32 [B, max(1, longest)] tensor padded with `fill` (core.py:848-853)."""
+    lens = np.fromiter((len(r) for r in rows), np.int64, len(rows))
+    out = np.full((len(rows), max(1, int(lens.max(initial=0)))), fill, np.int32)
+    total = int(lens.sum())
+    if total:
+        try:  # plain ints: no Python-level work per element
+            flat = np.fromiter(itertools.chain.from_iterable(rows), np.int32, total)
+        except (TypeError, ValueError):
+            flat = np.fromiter((int(x) for r in rows for x in r), np.int32, total)
+        out[np.arange(out.shape[1])[None, :] < lens[:, None]] = flat
+    return torch.from_numpy(out)
 
 
 class PhonemeTimestampAligner:
@@ -83,29 +99,33 @@ class PhonemeTimestampAligner:
         return res, conf, cstat, estimated
 
     def extract_timestamps_from_logits(self, logits_class, logits_group, spectral_lens, phoneme_sequences, wav_lens,
-                                       start_offset_times=0, group_sequences=None, do_groups=True):
+                                       start_offset_times=0, group_sequences=None, do_groups=True, as_arrays=False):
         """core.py:897-964 given the model's logits.  Returns list[B] of dicts with 'phoneme_timestamps' and
         'group_timestamps': lists of (id, start_frame, end_frame, target_seq_idx, is_estimated, confidence,
-        start_ms, end_ms)."""
+        start_ms, end_ms).  With `as_arrays` the same data as padded numpy arrays per head ({'rows' [B,cap,4],
+        'count' [B], 'is_estimated', 'confidence', 'start_ms', 'end_ms' [B,cap]}) for bulk consumers."""
         dev = self.device
         B = logits_class.shape[0]
         if isinstance(phoneme_sequences, torch.Tensor):
-            ph_seq_lens = [int((row != self.blank_class).sum()) for row in phoneme_sequences]  # core.py:844
-            ph = phoneme_sequences.to(torch.int32)
+            ph_seq_lens = (phoneme_sequences != self.blank_class).sum(dim=1).tolist()  # core.py:844
+            ph = phoneme_sequences.to(torch.int32).cpu()
         else:
             ph_seq_lens = [len(s) for s in phoneme_sequences]
-            smax = max(1, max(ph_seq_lens))
-            ph = torch.full((B, smax), self.blank_class, dtype=torch.int32)
-            for b, s in enumerate(phoneme_sequences):
-                ph[b, :len(s)] = torch.as_tensor(list(s), dtype=torch.int32)
-        if group_sequences is None:
-            rows = [self._map_phonemes_to_groups(ph[b, :ph_seq_lens[b]].tolist()) for b in range(B)]
-            group_sequences = rows
-        if not isinstance(group_sequences, torch.Tensor):
-            gmax = max(1, max(len(s) for s in group_sequences))
-            gr = torch.full((B, gmax), self.blank_group, dtype=torch.int32)
-            for b, s in enumerate(group_sequences):
-                gr[b, :len(s)] = torch.as_tensor(list(s), dtype=torch.int32)
+            ph = _pad_rows(phoneme_sequences, self.blank_class)
+        if group_sequences is None:  # core.py:868-871, as one table lookup over the padded batch
+            if self.phoneme_id_to_group_id is None:
+                raise ValueError("group_sequences not given and no phoneme_id_to_group_id mapping was configured")
+            ids = ph.numpy().astype(np.int64)
+            top = max(int(ids.max(initial=0)), max(self.phoneme_id_to_group_id, default=0)) + 1
+            lut = np.full(top, self.blank_group, np.int32)
+            for k, v in self.phoneme_id_to_group_id.items():
+                if 0 <= int(k) < top:
+                    lut[int(k)] = v
+            grp = np.where(ids >= 0, lut[np.clip(ids, 0, top - 1)], self.blank_group).astype(np.int32)
+            grp[np.arange(ids.shape[1])[None, :] >= np.asarray(ph_seq_lens)[:, None]] = self.blank_group
+            gr = torch.from_numpy(grp)
+        elif not isinstance(group_sequences, torch.Tensor):
+            gr = _pad_rows(group_sequences, self.blank_group)
         else:
             gr = group_sequences.to(torch.int32)
         spec = [int(x) for x in spectral_lens]
@@ -113,24 +133,57 @@ class PhonemeTimestampAligner:
         lp_g = log_softmax(logits_group.to(dev))
         heads = [("phoneme_timestamps", self.alignment_utils_p, lp_p, ph)]
         heads.append(("group_timestamps", self.alignment_utils_g, lp_g, gr))  # always runs (core.py:914)
+        pending = [(key, self._head(utils, lp, seqs, ph_seq_lens, spec)) for key, utils, lp, seqs in heads]
         out = [dict() for _ in range(B)]
-        pending = []
-        for key, utils, lp, seqs in heads:
-            pending.append((key, self._head(utils, lp, seqs, ph_seq_lens, spec)))
+        arrays = {}
         for key, (res, conf, cstat, estimated) in pending:
             res.raise_for_status()
             if int((cstat.cpu() != 0).sum()) != 0:
                 raise IndexError("confidence pass: phoneme id or start frame out of range")
-            cnt = res.seg_count.cpu().numpy()
-            segs = res.segs.cpu().numpy()
-            cf = conf.cpu().numpy()
-            for b in range(B):
-                rows = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), estimated[b][i] if estimated else False,
-                         float(cf[b, i])) for i, r in enumerate(segs[b, :cnt[b]])]
-                off = start_offset_times[b] if isinstance(start_offset_times, (list, tuple)) else start_offset_times
-                rows = convert_to_ms(rows, torch.tensor(spec[b]), off, wav_lens[b], self.resampler_sample_rate)
-                out[b][key] = sorted(rows, key=lambda x: x[6])  # core.py:955-956
-        return out
+            shaped = self._shape_rows(res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays)
+            if as_arrays:
+                arrays[key] = shaped
+            else:
+                for b in range(B):
+                    out[b][key] = shaped[b]
+        return arrays if as_arrays else out
+
+    def _shape_rows(self, res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays):
+        """core.py:939-956 for one head and the whole batch at once: convert_to_ms in the float32 tensor arithmetic
+        the reference ends up in (utils.py:128-146 with a 0-dim tensor `spectral_length`), then the rows as the
+        reference's 8-tuples -- or, with `as_arrays`, as padded numpy arrays (no per-row Python objects: on a
+        4096-utterance batch building the tuples costs far more than the device passes)."""
+        f32 = np.float32
+        cnt = res.seg_count.cpu().numpy()
+        segs = res.segs.cpu().numpy()
+        cf = conf.cpu().numpy()
+        B, cap = segs.shape[0], segs.shape[1]
+        sl = np.asarray(spec, np.int64)
+        dur = (np.asarray(wav_lens, np.float64) / float(self.resampler_sample_rate)).astype(f32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dpf = np.where(sl > 0, (f32(1) / sl.astype(f32)) * dur, f32(0)).astype(f32)
+        per_item = isinstance(start_offset_times, (list, tuple))
+        off = np.asarray(start_offset_times if per_item else [start_offset_times] * B, np.float64).astype(f32)
+        sms = ((off[:, None] + segs[:, :, 1].astype(f32) * dpf[:, None]) * f32(1000)).astype(f32)
+        ems = ((off[:, None] + segs[:, :, 2].astype(f32) * dpf[:, None]) * f32(1000)).astype(f32)
+        est = np.zeros((B, cap), bool)
+        if estimated:
+            for b, flags in enumerate(estimated):
+                est[b, :len(flags)] = flags
+        valid = np.arange(cap)[None, :] < cnt[:, None]
+        # core.py:955-956 sorts by start_ms; the rows come sorted by start frame, so this only ever reorders
+        # when two start frames round to out-of-order float32 times (never seen; handled for exactness)
+        bad = ((np.diff(sms, axis=1) < 0) & valid[:, 1:]).any(axis=1)
+        for b in np.nonzero(bad)[0]:
+            n = int(cnt[b])
+            order = np.argsort(sms[b, :n], kind="stable")
+            for a in (segs, cf, sms, ems, est):
+                a[b, :n] = a[b, :n][order]
+        if as_arrays:
+            return {"rows": segs, "count": cnt, "is_estimated": est, "confidence": cf[:, :cap], "start_ms": sms,
+                    "end_ms": ems}
+        cols = [segs[:, :, k].tolist() for k in range(4)] + [est.tolist(), cf[:, :cap].tolist(), sms.tolist(), ems.tolist()]
+        return [list(zip(*(c[b][:int(cnt[b])] for c in cols))) for b in range(B)]
 
     def extract_timestamps_from_segment_batch(self, wavs, wav_lens, phoneme_sequences, start_offset_times=0,
                                               group_sequences=None, extract_embeddings=False, do_groups=True,

@@ -80,6 +80,17 @@ def test_level2_pipeline_against_reference(gold, gpu_device):
             got_f = np.array([[r[5], r[6], r[7]] for r in rows], np.float32).reshape(-1, 3)
             np.testing.assert_allclose(got_f[:, 0], gf[:, 0], atol=2e-7, rtol=0)
             np.testing.assert_array_equal(got_f[:, 1:], gf[:, 1:])
+    # the same results as padded arrays (bulk consumers: no per-row Python objects)
+    arr = al.extract_timestamps_from_logits(lc, lg, spec, seqs, gold["l2_wav_lens"].tolist(),
+                                            start_offset_times=[0.5 * b for b in range(B)], group_sequences=groups,
+                                            as_arrays=True)
+    for key in ("phoneme_timestamps", "group_timestamps"):
+        a = arr[key]
+        for b in range(B):
+            n = int(a["count"][b])
+            rows = list(zip(*(a["rows"][b, :n, k].tolist() for k in range(4)), a["is_estimated"][b, :n].tolist(),
+                            a["confidence"][b, :n].tolist(), a["start_ms"][b, :n].tolist(), a["end_ms"][b, :n].tolist()))
+            assert rows == ts[b][key]
 
 
 def test_simplified_pipeline_against_reference(gold, gpu_device):

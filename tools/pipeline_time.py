@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""tools/pipeline_time.py [B] -- where the time of PhonemeTimestampAligner.extract_timestamps_from_logits goes on a
+headline-shaped batch (T=1000, S=40, both heads): device passes (HIP events) against the host-side shaping of the
+result into the reference's Python tuples."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from bournemouth_forced_aligner_amd import PhonemeTimestampAligner  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda", 0)
+T, S = 1000, 40
+lp, toks = bench.synth_batch(B, T, S, 67, 1003, dev)
+g = torch.Generator(device=dev)
+g.manual_seed(5)
+lg = torch.randn((B, T, 17), generator=g, device=dev)
+gmap = {p: p % 16 for p in range(66)}
+al = PhonemeTimestampAligner(device="cuda:0", phoneme_id_to_group_id=gmap)
+seqs = toks.cpu().tolist()
+spec = [T] * B
+wl = [T * 268] * B
+for as_arrays in (False, True):
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kw = {"as_arrays": True} if as_arrays else {}
+        out = al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"B={B} as_arrays={as_arrays}: {dt * 1e3:.1f} ms per call ({B * T / dt / 1e6:.1f} M frames/s through the API)")
+    if hasattr(al, "last_device_ms"):
+        print("   device passes:", {k: round(v, 3) for k, v in al.last_device_ms.items()})
+
+if os.environ.get("BFA_PROFILE_HOST"):
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, as_arrays=True)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
