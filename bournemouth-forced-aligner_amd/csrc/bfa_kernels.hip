@@ -268,10 +268,21 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
                     const float half = c / 2.0f; // :95 (a fresh tensor: stays constant)
                     int good = 1;
                     float mx = 0.0f;
-                    for (int f = s + 1; f < e; ++f) {
-                        const float v = expf_u10(lp[(int64_t)f * a.strideT + ph]);
-                        mx = (f == s + 1) ? v : __builtin_fmaxf(mx, v);
-                        if (v > half || v > 0.1f) { c = c + v; good++; } // :101-103
+                    // the lane's frames are one element per 268-byte row: eight independent (clamped) loads in
+                    // flight per lane, or the longest tuple of the wave pays one full memory latency per frame
+                    constexpr int U = 8;
+                    for (int f0 = s + 1; f0 < e; f0 += U) {
+                        float x[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) x[u] = lp[(int64_t)min(f0 + u, e - 1) * a.strideT + ph];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (f0 + u < e) {
+                                const float v = expf_u10(x[u]);
+                                mx = (f0 + u == s + 1) ? v : __builtin_fmaxf(mx, v);
+                                if (v > half || v > 0.1f) { c = c + v; good++; } // :101-103
+                            }
+                        }
                     }
                     if (good > 1) {
                         c = c / (float)good; // :105 -- this also lands in probs[start, ph] ...

@@ -80,7 +80,14 @@ __device__ __forceinline__ double seg_mean(const bfa_segment &g, const float *lp
     if (g.start < Tpad && g.phoneme < C && g.start < g.end) {
         const int ee = g.end > Tpad ? Tpad : g.end;
         double acc = 0.0;
-        for (int f = g.start; f < ee; ++f) acc += (double)expf_u10(lp[(int64_t)f * ld + g.phoneme]);
+        constexpr int U = 8; // independent (clamped) loads in flight: one element per 268-byte row
+        for (int f0 = g.start; f0 < ee; f0 += U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = lp[(int64_t)min(f0 + u, ee - 1) * ld + g.phoneme];
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (f0 + u < ee) acc += (double)expf_u10(x[u]);
+        }
         return (double)(float)(acc / (double)(ee - g.start));
     }
     return 0.001;

@@ -19,8 +19,10 @@ T, S = 1000, 40
 lp, toks = bench.synth_batch(B, T, S, 67, 1003, dev)
 g = torch.Generator(device=dev)
 g.manual_seed(5)
+gmap = {p: 1 + p % 15 for p in range(66)}  # no silence group among the targets, like the phoneme tokens
+lut = torch.tensor([gmap[p] for p in range(66)] + [16], device=dev)
 lg = torch.randn((B, T, 17), generator=g, device=dev)
-gmap = {p: p % 16 for p in range(66)}
+lg.scatter_add_(2, lut[lp.argmax(dim=-1)].unsqueeze(-1), torch.full((B, T, 1), 7.0, device=dev))  # planted like lp
 al = PhonemeTimestampAligner(device="cuda:0", phoneme_id_to_group_id=gmap)
 seqs = toks.cpu().tolist()
 spec = [T] * B
