@@ -137,6 +137,9 @@ constexpr int WIN_MAX_TOKENS = 64;
 // Window backpointers as lane masks written by the scalar unit (1) or as per-lane packed dwords (0, kept for A/B):
 // with masks the consumer spends one v_cmp per code bit (the result lands in an SGPR pair and leaves through
 // s_store_dwordx4) instead of v_cmp + v_addc, and K2 reads its frame's masks straight from memory (no LDS staging).
+#ifndef BFA_DBG_RELAX
+#define BFA_DBG_RELAX 0 // A/B builds of the packed-dword window variant: lets the (then unusable) wide classes compile
+#endif
 #ifndef BFA_WIN_SSTORE
 #define BFA_WIN_SSTORE 1
 #endif
