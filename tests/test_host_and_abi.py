@@ -301,3 +301,40 @@ def test_complete_target_coverage_matches_reference(host_gold):
         assert [list(r) for r in got] == c["expected"], f"case {i}"
         n_est += sum(1 for r in got if r[4])
     assert n_est > 500
+
+
+def test_batch_shaping_equals_per_row_convert_to_ms():
+    """_shape_rows (float32 ms arithmetic over the whole batch) against convert_to_ms row by row in the tensor mode
+    the reference ends up in (utils.py:115-149 with a 0-dim tensor spectral length), incl. the arrays mode."""
+    from types import SimpleNamespace
+    from bournemouth_forced_aligner_amd.utils import convert_to_ms
+    rng = np.random.default_rng(5)
+    al = _host_aligner()
+    B, cap = 9, 12
+    cnt = rng.integers(0, cap + 1, B).astype(np.int32)
+    segs = np.zeros((B, cap, 4), np.int32)
+    for b in range(B):
+        st = np.sort(rng.integers(0, 900, cnt[b]))
+        segs[b, :cnt[b], 0] = rng.integers(0, 66, cnt[b])
+        segs[b, :cnt[b], 1] = st
+        segs[b, :cnt[b], 2] = st + rng.integers(1, 30, cnt[b])
+        segs[b, :cnt[b], 3] = np.arange(cnt[b])
+    conf = rng.random((B, cap)).astype(np.float32)
+    spec = rng.integers(1, 1000, B).tolist()
+    spec[3] = 0
+    wav = (np.asarray(spec) * 268 + rng.integers(0, 200, B)).tolist()
+    offs = [0.0, 0.5, 1.25, 3.0, 10.1, 0.333, 7.0, 2.5, 100.25]
+    est = [[bool(x) for x in rng.integers(0, 2, cnt[b])] for b in range(B)]
+    res = SimpleNamespace(segs=torch.from_numpy(segs.copy()), seg_count=torch.from_numpy(cnt.copy()))
+    for offsets in (offs, 0.75):
+        rows = al._shape_rows(res, torch.from_numpy(conf.copy()), est, spec, wav, offsets, False)
+        arr = al._shape_rows(res, torch.from_numpy(conf.copy()), est, spec, wav, offsets, True)
+        for b in range(B):
+            off = offsets[b] if isinstance(offsets, list) else offsets
+            six = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), est[b][i], float(conf[b, i])) for i, r in enumerate(segs[b, :cnt[b]])]
+            exp = sorted(convert_to_ms(six, torch.tensor(spec[b]), off, wav[b], 16000), key=lambda x: x[6])
+            assert rows[b] == exp, f"item {b}"
+            n = int(arr["count"][b])
+            got = list(zip(*(arr["rows"][b, :n, k].tolist() for k in range(4)), arr["is_estimated"][b, :n].tolist(),
+                           arr["confidence"][b, :n].tolist(), arr["start_ms"][b, :n].tolist(), arr["end_ms"][b, :n].tolist()))
+            assert got == exp
