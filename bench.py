@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192, help="utterances timed on the host oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-window", action="store_true", help="A/B: full state layout instead of the sliding window")
+    ap.add_argument("--win-frames", type=int, default=0, help="A/B: window frame limit (bfa_params.reserved[2]), 0 = default")
+    ap.add_argument("--win-tokens", type=int, default=0, help="A/B: window token limit (bfa_params.reserved[1]), 0 = default")
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: mixed-length batch T~U{200..3000}, S=T//25 (BASELINE.json configs[3] per-GPU shard)")
     args = ap.parse_args()
@@ -289,6 +291,8 @@ def ragged_main(args, dev, rank, world):
     C, B = args.classes, args.batch
     lp, tk, T_len, S_len = synth_ragged(B, 200, 3000, C, 1004 + rank, dev)
     au = AlignmentUtils(blank_id=C - 1, silence_id=0)
+    au.viterbi_decoder.window_max_frames = args.win_frames or None
+    au.viterbi_decoder.window_max_tokens = args.win_tokens or None
     hint = au.viterbi_decoder.class_mask_hint(T_len.tolist(), S_len.tolist(), has_sil=False, n_classes=(None if NO_WINDOW else C))
     Td, Sd = T_len.to(dev), S_len.to(dev)
     for _ in range(2):

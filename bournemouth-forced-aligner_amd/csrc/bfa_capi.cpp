@@ -267,6 +267,7 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     a.p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
     a.p.class_mask = (uint32_t)params->reserved[0]; a.p.win_mask = 0;
     a.p.win_max_tokens = params->reserved[1] > 0 ? params->reserved[1] : bfa::WIN_MAX_TOKENS;
+    a.p.win_max_frames = params->reserved[2] > 0 ? params->reserved[2] : bfa::WIN_MAX_FRAMES;
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
     // one wavefront per work item; surplus items are taken by the blocks' stride loops
@@ -307,7 +308,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
     a.T_len = T_len; a.tokens = tokens; a.S_len = S_len;
     a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = 0;
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = 1; a.p.max_blanks = 10;
-    a.p.class_mask = 0; a.p.win_mask = 0; a.p.win_max_tokens = 0;
+    a.p.class_mask = 0; a.p.win_mask = 0; a.p.win_max_tokens = 0; a.p.win_max_frames = 0;
     // k_plan also writes seg_count/status: point them at scratch
     a.seg_count = a.uS; a.status = a.umode; a.seg_cap = 1;
     a.seg_count = (int32_t *)a.frame_ph; a.status = (int32_t *)a.frame_idx;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
             it.bw = band_standard(L);
             mode = BFA_MODE_STANDARD;
             // band narrow enough, and the utterance short enough in frames and tokens, for the window?
-            const int rw = (S <= p.win_max_tokens) ? win_class_for(L, it.bw, T) : 0;
+            const int rw = (S <= p.win_max_tokens) ? win_class_for(L, it.bw, T, p.win_max_frames) : 0;
             if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
         }
         (void)fallback_short;

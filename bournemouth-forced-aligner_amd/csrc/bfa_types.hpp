@@ -47,6 +47,7 @@ struct DevParams {
     uint32_t class_mask; // K1 classes to launch (host hint), 0 = derive from the shapes
     uint32_t win_mask;   // sliding-window classes the planner may use (bit Rw-1), set by bfa_launch_align
     int32_t win_max_tokens; // no window attempt for utterances with more tokens
+    int32_t win_max_frames; // ... or more frames
 };
 
 // everything the kernels of one bfa_align_batch call need; passed by value
@@ -145,9 +146,9 @@ constexpr int WIN_MAX_TOKENS = 64;
 #endif
 constexpr bool WIN_SSTORE = BFA_WIN_SSTORE != 0;
 __host__ __device__ inline int win_frames_per_word(int rw) { return rw == 1 ? 16 : (rw == 2 ? 8 : 4); }
-__host__ __device__ inline int win_class_for(int L, int bw, int Ts)
+__host__ __device__ inline int win_class_for(int L, int bw, int Ts, int max_frames = WIN_MAX_FRAMES)
 {
-    if (bw <= 0 || Ts > WIN_MAX_FRAMES) return 0;
+    if (bw <= 0 || Ts > max_frames) return 0;
     const int rfull = r_class_for_L(L);
     if (rfull == 0) return 0;
     constexpr int classes[6] = {1, 2, 3, 4, 6, 8}; // window states-per-lane classes

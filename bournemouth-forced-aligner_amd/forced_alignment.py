@@ -123,6 +123,7 @@ class ViterbiDecoder:
         # K1's sliding-window variant is only tried up to this many tokens (None = the library's 64); raise it for
         # posteriors that are known to keep path scores above the -1000 sentinel (bfa_params.reserved[1])
         self.window_max_tokens = None
+        self.window_max_frames = None   # likewise for the frame limit (bfa_params.reserved[2])
 
     def set_blank_id(self, blank_id):
         """forced_alignment.py:25-27"""
@@ -214,7 +215,8 @@ class ViterbiDecoder:
                 fits = (2 * bw + 1 + fpw + 2 + r + 1 <= 64 * r) & (r < rfull)
                 rw[fits] = r
             max_tok = self.window_max_tokens if self.window_max_tokens else self._WIN_MAX_TOKENS
-            rw[(bw <= 0) | (T > self._WIN_MAX_FRAMES) | (S > max_tok) | (ci > 6) | ~is_dp] = 0
+            max_frm = self.window_max_frames if self.window_max_frames else self._WIN_MAX_FRAMES
+            rw[(bw <= 0) | (T > max_frm) | (S > max_tok) | (ci > 6) | ~is_dp] = 0
         for r in np.unique(rw[rw > 0]):
             mask |= 1 << (7 + int(r))                            # (the rare sentinel rerun needs no hint bit)
         for c in np.unique(ci[is_dp & (rw == 0) & (ci <= 6)]):
@@ -261,6 +263,7 @@ class ViterbiDecoder:
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
         params.reserved[0] = int(class_mask)
         params.reserved[1] = int(self.window_max_tokens or 0)
+        params.reserved[2] = int(self.window_max_frames or 0)
         if seg_cap is None:
             seg_cap = Smax + 2 if self.ignore_noise else Tmax + 1
         L = _lib.lib()

@@ -90,7 +90,9 @@ typedef struct {
                                 [1] : window token limit, 0 = default (64).  K1's sliding-window variant is exact only while
                                 the path score stays above the reference's -1000 sentinel; otherwise the utterance is
                                 redone with the full state layout.  Every token costs the path a frame in a blank state,
-                                so utterances with more tokens than this are not tried in the window at all. */
+                                so utterances with more tokens than this are not tried in the window at all.
+                                [2] : window frame limit, 0 = default (1536): likewise for long utterances (scores are sums
+                                of per-frame log-probabilities). */
 } bfa_params;
 
 /* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),
