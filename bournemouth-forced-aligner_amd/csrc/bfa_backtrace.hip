@@ -190,7 +190,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
 // of maskA / maskB of slot r = A / B of state base + l*R + r at that frame (base = 0 without a window; A = c0 < best,
 // B = c1 < best; k = A ? (B ? 2 : 1) : 0).  Lane = frame: a lane keeps its frame's 2R masks in registers (loaded ahead,
 // coalesced), so a walk step is select / shift / ballot with no memory access.
-template <int R, bool WIN>
+template <int R, bool WIN, int NC = 1>
 __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
 {
     constexpr int FPW = (R == 1) ? 16 : (R == 2) ? 8 : 4;
@@ -243,7 +243,14 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
             // (window) a frame at which s lies outside the window is below the next move: its code is not used
             const int d = s - wbase;
             const int dc = min(max(d, 0), 64 * R - 1);
-            const int xl = dc / R, xr = dc - xl * R;
+            int xl, xr; // lane and mask slot of the state
+            if (NC == 1) { xl = dc / R; xr = dc - xl * R; }
+            else { // the layout split over NC consumer waves (bfa_dp5.inc): wave hh owns 64*RS contiguous states
+                constexpr int RS = R / NC;
+                const int hh = dc / (64 * RS), rem = dc - hh * 64 * RS;
+                xl = rem / RS;
+                xr = hh * RS + (rem - xl * RS);
+            }
             unsigned long long mA = mk[0], mB = mk[1];
 #pragma unroll
             for (int r = 1; r < R; ++r) { if (xr == r) { mA = mk[2 * r]; mB = mk[2 * r + 1]; } }
@@ -409,6 +416,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             default: if (WIN_SSTORE) walk_item_mask<8, true>(a, it, stok, lane); break;
             }
         } else {
+            if (it.split == 2) { // K1 split the DP over two consumer waves: per-frame lane masks (bfa_dp5.inc)
+                switch (r_class_for_L(it.L)) {
+                case 6: walk_item_mask<6, false, 2>(a, it, stok, lane); break;
+                default: walk_item_mask<8, false, 2>(a, it, stok, lane); break; // (R = 12, 16 are not split: 2R masks per frame would not fit K2's registers)
+                }
+            } else
             switch (r_class_for_L(it.L)) {
             case 2: walk_item<2, false>(a, it, sbp, stok, lane); break;
             case 3: walk_item<3, false>(a, it, sbp, stok, lane); break;

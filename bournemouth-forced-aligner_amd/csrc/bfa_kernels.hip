@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 
     Item it;
     it.kind = ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = T; it.tok0 = 0; it.nt = S; it.stride = 0; it.L = 0;
-    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.pad_ = 0;
+    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.split = 0;
     it.bp_off = (int64_t)b * a.bp_per_utt;
     int mode = BFA_MODE_EMPTY;
 

@@ -39,7 +39,13 @@ struct Item {
     int32_t anch_off;  // >= 0: offset of this DP's per-row silence-anchor counts in the utterance's pool; -1: none
     int64_t bp_off;    // dword offset of this item's backpointer block in the workspace
     int32_t win;       // > 0: K1 used the sliding in-band state window with `win` states per lane (bp: window layout)
-    int32_t pad_;
+    int32_t split;     // 2: K1 split the full layout over two consumer waves (bp: per-frame lane masks, bfa_dp5.inc)
+};
+
+// one wavefront's candidates for the final-state rule (forced_alignment.py:656-682) when a DP is spread over
+// several wavefronts (k_dp_big, k_dp5): rightmost / best state above the sentinel, best of all, dp[L-1], dp[L-2]
+struct BigFinal {
+    int rm; float bv; int bi; float av; int ai; float vL1, vL2;
 };
 
 struct DevParams {

@@ -103,6 +103,26 @@ def test_sliding_window_classes(ora, gpu_device, C):
                 _compare(res, exp, T_len)
 
 
+def test_split_consumer_classes(ora, gpu_device):
+    """Full-layout classes R = 6 and 8 (65..127 tokens at stride 4) run with the DP split over two consumer waves
+    (bfa_dp5.inc, per-frame lane masks, Item::split = 2): sharp and flat posteriors (sentinel regime with wrapped
+    backpointers), T from L to long utterances, T not a multiple of 16, both final-state rules."""
+    rng = np.random.default_rng(515)
+    C, blank = 67, 66
+    lps, toks = [], []
+    for S in (65, 80, 95, 96, 97, 110, 127):
+        for T in (4 * S + 1, 4 * S + 17, 6 * S + 5, 1537, 2999):
+            for peak in (9.0, 2.0, 0.3):
+                lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=peak, sigma=1.0, repeat_rate=0.15)
+                lps.append(lp)
+                toks.append(tk)
+    for lo in range(0, len(lps), 35):
+        lp, tk, T_len, S_len = cases.pad_batch(lps[lo:lo + 35], toks[lo:lo + 35], C, blank)
+        for tf in (True, False):
+            res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=0, tf=tf)
+            _compare(res, exp, T_len)
+
+
 def test_sliding_window_equals_full_layout(gpu_device):
     """The same batch through the window classes (hint bits 8-11) and through the full-layout classes only."""
     from bournemouth_forced_aligner_amd import AlignmentUtils
