@@ -191,12 +191,20 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
 // B = c1 < best; k = A ? (B ? 2 : 1) : 0).  Lane = frame: a lane keeps its frame's 2R masks in registers (loaded ahead,
 // coalesced), so a walk step is select / shift / ballot with no memory access.
 template <int R, bool WIN, int NC = 1>
-__device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
+__device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &it, uint32_t *sbp, int32_t *stok, int lane)
 {
     constexpr int FPW = (R == 1) ? 16 : (R == 2) ? 8 : 4;
     constexpr int FSH = (FPW == 16) ? 4 : (FPW == 8) ? 3 : 2;
-    constexpr int NPRE = (R <= 4) ? 3 : 1; // chunks in flight in registers (2R qwords per lane each)
+    // R <= 4: a lane keeps its frame's 2R masks in registers.  Wider layouts: the masks of ONE half of the slots (the
+    // half the walk is in; it changes at most a few times per utterance) are staged in LDS per chunk and a step reads
+    // its pair from there -- instead of a chain of R-1 vector selects per 64-bit mask, and without the register copy
+    // that limited these layouts to one chunk in flight.
+    constexpr bool STAGE = (R > 4);
+    constexpr int NPRE = STAGE ? 2 : 3;                     // chunks in flight in registers (2R qwords per lane each)
     constexpr int NQ = 2 * R;                              // 64-bit masks per frame
+    constexpr int HG = STAGE ? R / 2 : R;                  // slots per staged half
+    constexpr int LSTR = 2 * HG + 1;                       // qwords per lane in LDS (+1: bank spread)
+    unsigned long long *sm64 = reinterpret_cast<unsigned long long *>(sbp);
     const DevParams &p = a.p;
     const int b = it.utt;
     int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
@@ -229,11 +237,14 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
     auto walk_chunk = [&](unsigned long long (&buf)[NQ], int &bufb, int c) {
         const int t0 = c * 64;
         const int n = min(Ts - t0, 64); // frames in this chunk
-        unsigned long long mk[NQ];
+        unsigned long long mk[STAGE ? 1 : NQ];
+        if (!STAGE) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) mk[q] = buf[q];
+            for (int q = 0; q < NQ; ++q) mk[q] = buf[q];
+        }
         const int wbase = bufb;
-        fetch(buf, bufb, c - NPRE);
+        if (!STAGE) fetch(buf, bufb, c - NPRE); // (STAGE: the registers are needed until the chunk is walked)
+        int staged = -1;                        // STAGE: the half of the slots that is in LDS
         const int t = t0 + lane;
         unsigned long long todo = (n == 64) ? ~0ull : ((1ull << n) - 1ull); // frames the walk has not passed
         if (t0 == 0) todo &= ~1ull;                                          // frame 0 has no predecessor
@@ -251,9 +262,24 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
                 xl = rem / RS;
                 xr = hh * RS + (rem - xl * RS);
             }
-            unsigned long long mA = mk[0], mB = mk[1];
+            unsigned long long mA, mB;
+            if (!STAGE) {
+                mA = mk[0]; mB = mk[1];
 #pragma unroll
-            for (int r = 1; r < R; ++r) { if (xr == r) { mA = mk[2 * r]; mB = mk[2 * r + 1]; } }
+                for (int r = 1; r < R; ++r) { if (xr == r) { mA = mk[2 * r]; mB = mk[2 * r + 1]; } }
+            } else {
+                const int g = __builtin_amdgcn_readfirstlane(xr / HG); // wave-uniform like the walk state
+                if (g != staged) {
+                    wave_sync_lds();
+#pragma unroll
+                    for (int q = 0; q < 2 * HG; ++q) sm64[lane * LSTR + q] = (g == 0) ? buf[q] : buf[(2 * HG + q) < NQ ? 2 * HG + q : 0];
+                    wave_sync_lds();
+                    staged = g;
+                }
+                const int qq = xr - g * HG;
+                mA = sm64[lane * LSTR + 2 * qq];
+                mB = sm64[lane * LSTR + 2 * qq + 1];
+            }
             const bool inw = (unsigned)d < (unsigned)(64 * R);
             const unsigned A = inw ? (unsigned)((mA >> xl) & 1ull) : 0u;
             const unsigned long long mv = __ballot(A != 0u) & todo;
@@ -266,6 +292,7 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
             hi = jl - 1;
             todo &= (1ull << jl) - 1ull;
         }
+        if (STAGE) fetch(buf, bufb, c - NPRE); // behind the walk: its loads overlap the stores below and the next chunk
         if (lane < n) {
             const int o = t - it.pad_left; // :447-448 trim the boundary padding
             if (o >= 0 && o < it.nout) {
@@ -358,7 +385,7 @@ __device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it
 // (4 waves per SIMD: a 4096-utterance batch is resident at once)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_backtrace(AlignArgs a)
 {
-    __shared__ uint32_t sbp[16 * 64]; // one chunk: <= 1024 dwords
+    __shared__ __attribute__((aligned(16))) uint32_t sbp[18 * 64]; // one chunk: <= 1024 dwords (dword layouts) / 9 qwords per lane (staged masks)
     __shared__ int32_t stok[1024];    // the item's tokens (nt <= L <= 1024)
     const int lane = threadIdx.x & 63;
     const DevParams &p = a.p;
@@ -408,18 +435,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
         if (it.win > 0) {
             switch (it.win) {
-            case 1: if (WIN_SSTORE) walk_item_mask<1, true>(a, it, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
-            case 2: if (WIN_SSTORE) walk_item_mask<2, true>(a, it, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
-            case 3: if (WIN_SSTORE) walk_item_mask<3, true>(a, it, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
-            case 4: if (WIN_SSTORE) walk_item_mask<4, true>(a, it, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
-            case 6: if (WIN_SSTORE) walk_item_mask<6, true>(a, it, stok, lane); break;
-            default: if (WIN_SSTORE) walk_item_mask<8, true>(a, it, stok, lane); break;
+            case 1: if (WIN_SSTORE) walk_item_mask<1, true>(a, it, sbp, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
+            case 2: if (WIN_SSTORE) walk_item_mask<2, true>(a, it, sbp, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
+            case 3: if (WIN_SSTORE) walk_item_mask<3, true>(a, it, sbp, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
+            case 4: if (WIN_SSTORE) walk_item_mask<4, true>(a, it, sbp, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
+            case 6: if (WIN_SSTORE) walk_item_mask<6, true>(a, it, sbp, stok, lane); break;
+            default: if (WIN_SSTORE) walk_item_mask<8, true>(a, it, sbp, stok, lane); break;
             }
         } else {
             if (it.split == 2) { // K1 split the DP over two consumer waves: per-frame lane masks (bfa_dp5.inc)
                 switch (r_class_for_L(it.L)) {
-                case 6: walk_item_mask<6, false, 2>(a, it, stok, lane); break;
-                default: walk_item_mask<8, false, 2>(a, it, stok, lane); break; // (R = 12, 16 are not split: 2R masks per frame would not fit K2's registers)
+                case 6: walk_item_mask<6, false, 2>(a, it, sbp, stok, lane); break;
+                default: walk_item_mask<8, false, 2>(a, it, sbp, stok, lane); break; // (R = 12, 16 are not split: 2R masks per frame would not fit K2's registers)
                 }
             } else
             switch (r_class_for_L(it.L)) {
