@@ -445,6 +445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         } else {
             if (it.split == 2) { // K1 split the DP over two consumer waves: per-frame lane masks (bfa_dp5.inc)
                 switch (r_class_for_L(it.L)) {
+                case 4: walk_item_mask<4, false, 2>(a, it, sbp, stok, lane); break;
                 case 6: walk_item_mask<6, false, 2>(a, it, sbp, stok, lane); break;
                 default: walk_item_mask<8, false, 2>(a, it, sbp, stok, lane); break; // (R = 12, 16 are not split: 2R masks per frame would not fit K2's registers)
                 }
