@@ -104,9 +104,10 @@ def test_sliding_window_classes(ora, gpu_device, C):
 
 
 def test_split_consumer_classes(ora, gpu_device):
-    """Full-layout classes R = 6 and 8 (65..127 tokens at stride 4) run with the DP split over two consumer waves
-    (bfa_dp5.inc, per-frame lane masks, Item::split = 2): sharp and flat posteriors (sentinel regime with wrapped
-    backpointers), T from L to long utterances, T not a multiple of 16, both final-state rules."""
+    """Full-layout classes R = 6 and 8 (65..127 tokens at stride 4); R = 8 runs with the DP split over two consumer
+    waves (bfa_dp5.inc, per-frame lane masks, Item::split = 2; R = 6 too in BFA_SPLIT_R6 builds): sharp and flat
+    posteriors (sentinel regime with wrapped backpointers), T from L to long utterances, T not a multiple of 16, both
+    final-state rules."""
     rng = np.random.default_rng(515)
     C, blank = 67, 66
     lps, toks = [], []
