@@ -340,3 +340,55 @@ def test_batch_shaping_equals_per_row_convert_to_ms():
             got = list(zip(*(arr["rows"][b, :n, k].tolist() for k in range(4)), arr["is_estimated"][b, :n].tolist(),
                            arr["confidence"][b, :n].tolist(), arr["start_ms"][b, :n].tolist(), arr["end_ms"][b, :n].tolist()))
             assert got == exp
+
+
+def _bench_json(argv, timeout=600):
+    """Run bench.py as the driver does (a fresh process) and parse the one JSON line rank 0 prints."""
+    import json
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_dry_run_spawns_two_ranks_that_agree_on_the_partition():
+    """`bench.py --gpus 2` started by hand must itself become two ranks; --dry-run = gloo, no GPU work:
+    the C4 plan (lengths -> LPT partition) is computed by both ranks and compared, and the packed gather runs."""
+    out = _bench_json(["--gpus", "2", "--dry-run", "--config", "c4", "--global-batch", "4096"])
+    assert out["dry_run"] and out["n_gpus"] == 2
+    assert len(out["ranks"]) == 2 and len({r["pid"] for r in out["ranks"]}) == 2
+    assert [r["rank"] for r in out["ranks"]] == [0, 1]
+    assert out["shard_agree"] and out["gather_ok"]
+    assert sum(out["shard_sizes"]) == 4096 and out["load_imbalance_max_over_mean"] < 1.01
+    head = _bench_json(["--gpus", "2", "--dry-run"])
+    assert head["n_gpus"] == 2 and head["gather_ok"]
+
+
+def test_c4_generator_is_a_function_of_the_global_index_only():
+    """tools/synth.py: an utterance's posteriors must not depend on the batch it is synthesised in (that is what lets
+    each rank make only its shard and rank 0 re-make the parity sample)."""
+    from tools import synth
+    T, S = synth.c4_lengths(5000, seed=1004)
+    assert T.min() >= 200 and T.max() <= 3000 and (S == np.maximum(1, T // 25)).all()
+    T2, _ = synth.c4_lengths(100, seed=1004)
+    np.testing.assert_array_equal(T[:100], T2)
+    small = np.argsort(T)[:6]
+    a_idx, b_idx = small[[0, 2, 4, 5]], small[[5, 1, 2]]
+    la, ta = synth.c4_utterances(a_idx, T[a_idx], S[a_idx], 67, 1004, "cpu")
+    lb, tb = synth.c4_utterances(b_idx, T[b_idx], S[b_idx], 67, 1004, "cpu", Tpad=400, Spad=20)
+    for (i, j) in ((3, 0), (1, 2)):
+        g = a_idx[i]
+        assert g == b_idx[j]
+        assert torch.equal(la[i, :T[g]], lb[j, :T[g]]) and torch.equal(ta[i, :S[g]], tb[j, :S[g]])
+    ca, cb = synth.input_checksum(la, T[a_idx]), synth.input_checksum(lb, T[b_idx])
+    assert int(ca[3]) == int(cb[0]) and int(ca[1]) == int(cb[2]) and int(ca[0]) != int(ca[1])
+    # a planted path: every token id appears as the arg-max of some frame, in order
+    am = la[0, :T[a_idx[0]]].argmax(-1).numpy()
+    runs = am[np.r_[True, am[1:] != am[:-1]]]
+    assert [int(x) for x in runs if x != 66] == [int(x) for x in ta[0, :S[a_idx[0]]]]
