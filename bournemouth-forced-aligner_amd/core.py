@@ -34,17 +34,49 @@ def _pad_rows(rows, fill):
 
 
 class PhonemeTimestampAligner:
-    def __init__(self, posterior_fn=None, phonemizer=None, phoneme_id_to_group_id=None, blank_class=66,
-                 silence_class=0, blank_group=16, silence_group=0, device="cuda", silence_anchors=10,
-                 boost_targets=True, enforce_minimum=True, enforce_all_targets=True, ensure_completeness=False,
-                 ignore_noise=True, extend_soft_boundaries=True, boundary_softness=3, sample_rate=16000,
-                 phoneme_id_to_label=None, group_id_to_label=None):
+    """Mirror of core.py:34-234 at class level.  The positional / keyword arguments of the reference constructor are
+    accepted with their defaults; the acoustic model and the espeak phonemiser are outside this package, so
+
+    * `preset` / `model_name` / `cupe_ckpt_path` select nothing here: no checkpoint is ever loaded.  The posterior
+      producer is the keyword-only `posterior_fn` (the CUPE model on PyTorch-ROCm in production, anything in tests);
+      without one `self.extractor` stays None and the extraction entry points raise the reference's own
+      "model is not loaded" error (core.py:886) -- exactly what the reference does after `preset=None`;
+    * `lang` is only recorded (the injected `phonemizer` owns the language);
+    * `mapper` other than "ph66" raises like core.py:141-142; `duration_max` sets `wav_len_max` (core.py:136-138).
+    """
+
+    def __init__(self, preset="en-us", model_name=None, cupe_ckpt_path=None, lang="en-us", mapper="ph66",
+                 duration_max=30, device="auto", silence_anchors=10, boost_targets=True, enforce_minimum=True,
+                 enforce_all_targets=True, ensure_completeness=False, ignore_noise=True, extend_soft_boundaries=True,
+                 boundary_softness=3, bad_confidence_threshold=0.6, *, posterior_fn=None, phonemizer=None,
+                 phoneme_id_to_group_id=None, blank_class=66, silence_class=0, blank_group=16, silence_group=0,
+                 sample_rate=16000, phoneme_id_to_label=None, group_id_to_label=None):
+        self.warn_level = 1
+        if device == "auto":
+            device = "cuda"  # this package has no CPU implementation of the alignment path
+        self.device = torch.device(device)
+        self.preset, self.model_name, self.cupe_ckpt_path = preset, model_name, cupe_ckpt_path
+        self.lang = lang
         self.posterior_fn = posterior_fn
+        self.extractor = posterior_fn  # the reference's attribute name for "the model" (None = not loaded)
         self.phonemizer = phonemizer
-        self.phoneme_id_to_group_id = phoneme_id_to_group_id
+        self.resampler_sample_rate = sample_rate
+        self.sample_rate = sample_rate
+        self.padding_ph_label = -100
+        self.ph_seq_min = 1
+        self.seg_duration_min = 0.05
+        self.seg_duration_min_samples = int(self.seg_duration_min * self.resampler_sample_rate)
+        self.seg_duration_max = duration_max
+        self.wav_len_max = int(self.seg_duration_max * self.resampler_sample_rate)
+        self.selected_mapper = mapper
+        if self.selected_mapper != "ph66":
+            raise ValueError("Currently only 'ph66' mapper is supported.")
+        self.phonemes_key = getattr(phonemizer, "phonemes_key", "ph66")
+        self.phoneme_groups_key = getattr(phonemizer, "phoneme_groups_key", "pg16")
+        self.phoneme_id_to_group_id = phoneme_id_to_group_id if phoneme_id_to_group_id is not None else \
+            getattr(phonemizer, "phoneme_id_to_group_id", None)
         self.blank_class, self.silence_class = blank_class, silence_class
         self.blank_group, self.silence_group = blank_group, silence_group
-        self.device = torch.device(device)
         self.silence_anchors = silence_anchors
         self.boost_targets = boost_targets
         self.enforce_minimum = enforce_minimum
@@ -53,10 +85,63 @@ class PhonemeTimestampAligner:
         self.ignore_noise = ignore_noise
         self.extend_soft_boundaries = extend_soft_boundaries
         self.boundary_softness = boundary_softness
-        self.resampler_sample_rate = sample_rate
-        self.phoneme_id_to_label = phoneme_id_to_label or {}
-        self.group_id_to_label = group_id_to_label or {}
+        self.bad_confidence_threshold = bad_confidence_threshold
+        self.phoneme_id_to_label = phoneme_id_to_label or getattr(phonemizer, "index_to_plabel", None) or {}
+        self.group_id_to_label = group_id_to_label or getattr(phonemizer, "index_to_glabel", None) or {}
         self._setup_decoders()
+        self.reset_counters()
+
+    def reset_counters(self):
+        """core.py:184-194"""
+        self.total_segments_processed = 0
+        self.total_segments_bad = 0
+        self.total_segments_failed = 0
+        self.total_phonemes_aligned = 0
+        self.total_phonemes_target = 0
+        self.total_phonemes_aligned_easily = 0
+        self.total_phonemes_missed = 0
+        self.total_phonemes_extra = 0
+        self.perfect_matches = 0
+
+    def phonemize_sentence(self, text):
+        """core.py: the injected phonemiser (a callable, or an object with .phonemize_sentence like the reference's
+        ph66 Phonemizer)."""
+        if self.phonemizer is None:
+            raise ValueError("process_segments needs a phonemizer (espeak is not part of this package): pass "
+                             "phonemizer=callable(text) -> {'ph66': [...], 'pg16': [...], ...}")
+        fn = getattr(self.phonemizer, "phonemize_sentence", None) or self.phonemizer
+        return fn(text)
+
+    @staticmethod
+    def _rms_normalize(audio):
+        """core.py:314-320"""
+        rms = torch.sqrt(torch.mean(audio ** 2))
+        if rms > 0:
+            audio = audio / rms
+        return audio
+
+    @torch.no_grad()
+    def chop_wav(self, wav, start_frame, end_frame):
+        """core.py:276-311: slice [C, start:end], channel mean, RMS normalise, pad / truncate to wav_len_max.
+        Returns (wav, wav_len, error_code)."""
+        num_frames = (end_frame - start_frame) if (end_frame != -1) else -1
+        if num_frames < self.seg_duration_min_samples:
+            print(f"ERROR: Segment too short: {num_frames} frames, minimum required is {self.seg_duration_min_samples} frames.")
+            return None, None, -1
+        wav = wav[:, start_frame:end_frame]
+        assert (wav.shape[1] <= num_frames) or (num_frames == -1)
+        if wav.shape[1] < self.seg_duration_min_samples:
+            print(f"Wav shape is too small: {wav.shape}, start_frame: {start_frame}, end_frame: {end_frame}")
+            return None, None, -2
+        wav = wav.mean(dim=0)
+        wav = self._rms_normalize(wav)
+        wav_len = wav.shape[0]
+        if wav_len > self.wav_len_max:
+            wav = wav[:self.wav_len_max]
+            wav_len = wav.shape[0]
+        else:
+            wav = torch.nn.functional.pad(wav, (0, self.wav_len_max - wav.shape[0]), "constant", 0)
+        return wav, wav_len, 0
 
     def _setup_decoders(self):
         """core.py:252-257"""
@@ -388,63 +473,157 @@ class PhonemeTimestampAligner:
 
     def process_segments(self, srt_data, audio_wavs, extract_embeddings=False, do_groups=False, batch_size=16,
                          debug=False):
-        """core.py:1212-1470: srt_data = {'segments': [{'start','end','text'}, ...]} (or a list of those, one per
-        clip).  Needs the injected phonemizer and posterior_fn."""
-        if self.phonemizer is None:
-            raise ValueError("process_segments needs a phonemizer(text) callable (espeak is not part of this package)")
-        single = isinstance(srt_data, dict)
-        clips = [srt_data] if single else list(srt_data)
-        wavs = [audio_wavs] if single or isinstance(audio_wavs, torch.Tensor) and audio_wavs.dim() == 1 else list(audio_wavs)
-        results = []
-        for clip, wav in zip(clips, wavs):
-            wav = wav.reshape(-1) if isinstance(wav, torch.Tensor) else torch.as_tensor(wav).reshape(-1)
-            segs_out = []
-            segs = clip["segments"]
-            for i0 in range(0, len(segs), batch_size):
-                chunk = segs[i0:i0 + batch_size]
-                tss = [self.phonemizer(s["text"]) for s in chunk]
-                pieces, lens = [], []
-                for s in chunk:
-                    a = int(s["start"] * self.resampler_sample_rate)
-                    e = int(s["end"] * self.resampler_sample_rate)
-                    pieces.append(wav[a:e])
-                    lens.append(int(pieces[-1].numel()))
-                wmax = max(lens)
-                batch = torch.zeros((len(chunk), wmax), dtype=torch.float32)
-                for b, pc in enumerate(pieces):
-                    batch[b, :lens[b]] = pc
-                seqs = [list(t["ph66"]) for t in tss]
-                groups = [list(t["pg16"]) for t in tss] if all("pg16" in t for t in tss) else None
+        """core.py:1212-1487, step for step: normalise the inputs (a dict -> a one-clip batch; a (C,T) / (B,C,T) tensor
+        -> list of (C,T) clips), flatten the sub-segments of all clips, phonemise, drop sequences shorter than
+        `ph_seq_min`, chop + RMS-normalise + pad the audio (`chop_wav`), run the extraction in one call -- or, when
+        `batch_size < number of segments`, in slices whose `ValueError` ("Audio too short to align", core.py:1367-1386)
+        turns that slice into empty results; in the one-call branch the error propagates like in the reference --
+        post-process, regroup per clip, then the confidence analysis that can set `coverage_analysis.bad_alignment`.
+        Always returns a list with one {'segments': [...]} per clip."""
+        if extract_embeddings:
+            raise NotImplementedError("extract_embeddings=True is outside the accelerated path")
+        if isinstance(audio_wavs, torch.Tensor):
+            if audio_wavs.dim() == 3:
+                audio_wavs = [audio_wavs[i] for i in range(audio_wavs.size(0))]
+            elif audio_wavs.dim() == 2:
+                audio_wavs = [audio_wavs]
+            else:
+                raise ValueError(f"Expected audio_wavs of 2D (C,T) or 3D (B,C,T), got {audio_wavs.dim()}D")
+        if isinstance(srt_data, dict):
+            srt_data = [srt_data]
+        if len(srt_data) != len(audio_wavs):
+            raise ValueError(f"Batch size mismatch: {len(srt_data)} srt items vs {len(audio_wavs)} audio waveforms.")
+        for bi, batch_item in enumerate(srt_data):
+            if "segments" not in batch_item:
+                raise ValueError(f"Batch item {bi} missing 'segments' key. Keys: {list(batch_item.keys())}")
+            for si, seg in enumerate(batch_item["segments"]):
+                if not all(k in seg for k in ("start", "end", "text")):
+                    raise ValueError(f"Batch {bi}, segment {si} missing required keys (start/end/text). Has: {list(seg.keys())}")
+        num_batch = len(srt_data)
+        flat_items = [(bi, seg, clip_wav) for bi, (item, clip_wav) in enumerate(zip(srt_data, audio_wavs))
+                      for seg in item["segments"]]
+        if not flat_items:
+            return [{"segments": []} for _ in range(num_batch)]
+
+        ts_outs = [self.phonemize_sentence(seg["text"]) for _, seg, _ in flat_items]
+        phoneme_sequences = [ts[self.phonemes_key] for ts in ts_outs]
+        group_sequences = [ts[self.phoneme_groups_key] for ts in ts_outs] if do_groups else [None] * len(flat_items)
+        for (_, seg, _), ph_seq, grp_seq in zip(flat_items, phoneme_sequences, group_sequences):
+            seg[self.phonemes_key] = ph_seq          # (the reference writes these into the caller's dicts too)
+            seg[self.phoneme_groups_key] = grp_seq
+        valid = []
+        for i, ((bi, seg, _), ph_seq) in enumerate(zip(flat_items, phoneme_sequences)):
+            if not ph_seq or len(ph_seq) < self.ph_seq_min:
+                if debug or self.warn_level >= 1:
+                    print(f"Skipping clip {bi}, segment '{seg.get('text', '')[:30]}': insufficient phoneme sequence "
+                          f"({len(ph_seq) if ph_seq else 0})")
+                continue
+            valid.append(i)
+        batch_results = [{"segments": []} for _ in range(num_batch)]
+        if not valid:
+            return batch_results
+        flat_f = [flat_items[i] for i in valid]
+        ph_f = [phoneme_sequences[i] for i in valid]
+        grp_f = [group_sequences[i] for i in valid]
+        ts_f = [ts_outs[i] for i in valid]
+
+        chopped = [self.chop_wav(clip_wav, int(seg["start"] * self.resampler_sample_rate),
+                                 int(seg["end"] * self.resampler_sample_rate)) for _, seg, clip_wav in flat_f]
+        wavs, wav_lens, codes = zip(*chopped)
+        keep = [i for i, code in enumerate(codes) if code == 0]
+        if len(keep) < len(flat_f):
+            if debug or self.warn_level >= 1:
+                for i, code in enumerate(codes):
+                    if code != 0:
+                        bi, seg, _ = flat_f[i]
+                        print(f"Skipping clip {bi}, segment start: {seg['start']}, end: {seg['end']} due to chopping error ({code})")
+            flat_f = [flat_f[i] for i in keep]
+            ph_f = [ph_f[i] for i in keep]
+            grp_f = [grp_f[i] for i in keep]
+            ts_f = [ts_f[i] for i in keep]
+            wavs = [wavs[i] for i in keep]
+            wav_lens = [wav_lens[i] for i in keep]
+        if not wavs:
+            raise ValueError("All segments have audio chopping errors. Cannot proceed with timestamp extraction.")
+        wavs = torch.stack(list(wavs), dim=0)
+        wav_lens = list(wav_lens)
+        start_times = [seg["start"] for _, seg, _ in flat_f]
+
+        if batch_size < len(flat_items):  # (the reference compares with the UNfiltered count)
+            results = []
+            for i in range(0, len(flat_f), batch_size):
+                sl = slice(i, i + batch_size)
                 try:
-                    ts_dicts, _, _ = self.extract_timestamps_from_segment_batch(
-                        batch, lens, seqs, start_offset_times=[s["start"] for s in chunk], group_sequences=groups,
-                        extract_embeddings=False, do_groups=do_groups, debug=debug)
-                except ValueError:
-                    ts_dicts = [None] * len(chunk)  # core.py:1367-1386: the chunk yields empty results
-                for s, t, d in zip(chunk, tss, ts_dicts):
-                    if d is None:
-                        segs_out.append(dict(s, phoneme_ts=[], group_ts=[]))
-                    else:
-                        segs_out.append(self._post_process_segment(s, t, d["phoneme_timestamps"],
-                                                                   d["group_timestamps"] if do_groups else None))
-            results.append({"segments": segs_out})
-        return results[0] if single else results
+                    part, _, _ = self.extract_timestamps_from_segment_batch(
+                        wavs[sl], wav_lens[sl], ph_f[sl], start_offset_times=start_times[sl],
+                        group_sequences=grp_f[sl] if do_groups else None, extract_embeddings=False,
+                        do_groups=do_groups, debug=debug)
+                    results.extend(part)
+                except ValueError as ex:
+                    if debug or self.warn_level >= 1:
+                        print(f"ValueError processing batch {sl}: {ex}. This may be due to audio duration too short for "
+                              f"the phoneme sequence.")
+                    results.extend([{"phoneme_timestamps": [], "group_timestamps": []} for _ in range(batch_size)])
+        else:
+            results, _, _ = self.extract_timestamps_from_segment_batch(
+                wavs, wav_lens, ph_f, start_offset_times=start_times, group_sequences=grp_f if do_groups else None,
+                extract_embeddings=False, do_groups=do_groups, debug=debug)
+
+        for (bi, seg, _), result, ts in zip(flat_f, results, ts_f):
+            processed = self.post_process_segment(seg, ts, seg[self.phonemes_key], result["phoneme_timestamps"],
+                                                  result["group_timestamps"] if do_groups else None, debug=debug)
+            batch_results[bi]["segments"].append(processed)
+        self._confidence_analysis(batch_results, debug)
+        return batch_results
+
+    def _confidence_analysis(self, batch_results, debug=False):
+        """core.py:1420-1470: counters, and `coverage_analysis.bad_alignment` for long segments with too many
+        low-confidence phonemes or a confident-start / lost-end pattern."""
+        for bi, batch_item in enumerate(batch_results):
+            for si, seg_out in enumerate(batch_item["segments"]):
+                self.total_segments_processed += 1
+                if not seg_out.get("phoneme_ts"):
+                    self.total_segments_failed += 1
+                    continue
+                phoneme_ts = seg_out["phoneme_ts"]
+                if [t["phoneme_id"] for t in phoneme_ts] == seg_out[self.phonemes_key]:
+                    self.perfect_matches += 1
+                if len(phoneme_ts) > 60:
+                    confidences = [t["confidence"] for t in phoneme_ts]
+                    low_ratio = sum(1 for c in confidences if c < 0.5) / len(confidences)
+                    if low_ratio > self.bad_confidence_threshold:
+                        seg_out["coverage_analysis"]["bad_alignment"] = True
+                        self.total_segments_bad += 1
+                    first_20 = sum(confidences[10:30]) / 20
+                    last_20 = sum(confidences[-30:-10]) / 20
+                    if first_20 > 0.1 and last_20 < 0.1:
+                        if self.silence_anchors == 0:
+                            raise Exception(f"Bad confidence pattern in clip {bi}, segment {si+1}: first 20 avg "
+                                            f"{first_20:.3f} vs last 20 avg {last_20:.3f}. Consider setting `silence_anchors=3`.")
+                        seg_out["coverage_analysis"]["bad_alignment"] = True
+                        self.total_segments_bad += 1
 
     def process_sentence(self, text, audio_wav, extract_embeddings=False, do_groups=False, debug=False):
-        """core.py:1553-1584: one sentence, one clip."""
-        wav = audio_wav if isinstance(audio_wav, torch.Tensor) else torch.as_tensor(np.asarray(audio_wav))
-        dur = wav.reshape(-1).numel() / self.resampler_sample_rate
-        srt = {"segments": [{"start": 0.0, "end": dur, "text": text}]}
-        return self.process_segments(srt, wav, extract_embeddings=extract_embeddings, do_groups=do_groups, debug=debug)
+        """core.py:1553-1584: one sentence, one (C, T) clip (a 1-D waveform is taken as one channel)."""
+        audio_wav = self._as_clip(audio_wav)
+        duration = audio_wav.shape[1] / self.sample_rate
+        srt_data = [{"segments": [{"start": 0.0, "end": duration, "text": text.strip()}]}]
+        return self.process_segments(srt_data, [audio_wav], extract_embeddings=extract_embeddings, do_groups=do_groups,
+                                     debug=debug)[0]
 
-    def process_sentences_batch(self, texts, audio_wavs, extract_embeddings=False, do_groups=False, batch_size=16,
-                                debug=False):
+    def process_sentences_batch(self, texts, audio_wavs, extract_embeddings=False, do_groups=False, debug=False):
         """core.py:1586-1616: one sentence per clip."""
-        srts = []
-        for text, w in zip(texts, audio_wavs):
-            n = (w if isinstance(w, torch.Tensor) else torch.as_tensor(np.asarray(w))).reshape(-1).numel()
-            srts.append({"segments": [{"start": 0.0, "end": n / self.resampler_sample_rate, "text": text}]})
-        return self.process_segments(srts, list(audio_wavs), extract_embeddings=extract_embeddings, do_groups=do_groups,
-                                     batch_size=batch_size, debug=debug)
+        assert len(texts) == len(audio_wavs), \
+            f"Number of texts ({len(texts)}) must match number of audio waveforms ({len(audio_wavs)})"
+        audio_wavs = [self._as_clip(w) for w in audio_wavs]
+        srt_data = [{"segments": [{"start": 0.0, "end": w.shape[1] / self.sample_rate, "text": text.strip()}]}
+                    for text, w in zip(texts, audio_wavs)]
+        return self.process_segments(srt_data, audio_wavs, extract_embeddings=extract_embeddings, do_groups=do_groups,
+                                     debug=debug)
+
+    @staticmethod
+    def _as_clip(w):
+        w = w if isinstance(w, torch.Tensor) else torch.as_tensor(np.asarray(w))
+        return w.unsqueeze(0) if w.dim() == 1 else w
 
     process_batch = process_sentences_batch  # the name BASELINE.json uses

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
                 const int ph = sg[i].phoneme;
                 const int s = max(0, sg[i].start), e = min(T, sg[i].end); // :86-87
                 if (s >= T || ph < 0 || ph >= a.C) { bad = 1; cf[i] = 0.0f; continue; } // IndexError at :89
-                float c = expf_u10(lp[(int64_t)s * a.strideT + ph]);
+                float c = exp_cr(lp[(int64_t)s * a.strideT + ph]);
                 if (s < e) {
                     const float half = c / 2.0f; // :95 (a fresh tensor: stays constant)
                     int good = 1;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             if (f0 + u < e) {
-                                const float v = expf_u10(x[u]);
+                                const float v = exp_cr(x[u]);
                                 mx = (f0 + u == s + 1) ? v : __builtin_fmaxf(mx, v);
                                 if (v > half || v > 0.1f) { c = c + v; good++; } // :101-103
                             }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
                 auto prob = [&](int f, int ph, int upto) -> float {
                     for (int k = upto; k >= 0; --k)
                         if (mflag[k] && sg[k].phoneme == ph && max(0, sg[k].start) == f) return mval[k];
-                    return expf_u10(lp[(int64_t)f * a.strideT + ph]);
+                    return exp_cr(lp[(int64_t)f * a.strideT + ph]);
                 };
                 for (int i = 0; i < n; ++i) {
                     const int ph = sg[i].phoneme;

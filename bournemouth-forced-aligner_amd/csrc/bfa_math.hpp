@@ -39,6 +39,37 @@ __device__ __forceinline__ float expf_u10(float d)
     return u;
 }
 
+// torch.exp on a float32 CPU tensor (forced_alignment.py:503, utils.py:81, core.py:704) is MKL VML's vsExp, whose
+// algorithm is not published; measured, it equals the CORRECTLY ROUNDED float32 exponential on 98.9 % of inputs
+// (<= 1 ulp on the rest; Sleef's expf_u10 only matches it on 90 %).  So it is restated as a float64 exponential
+// (Taylor to r^13 on |r| <= ln2/2, error < 2^-56) rounded once to float32 -- IEEE float64 ops and explicit fma only,
+// the same sequence as oracle/bfa_oracle.c::ora_exp_cr, hence the same bits.  Used by the silence-probability,
+// confidence and soft-boundary passes (one element per row: the float64 rate does not matter there).
+__device__ __forceinline__ float exp_cr(float xf)
+{
+    const double x = (double)xf;
+    if (!(x > -104.0)) return (x != x) ? xf : 0.0f;
+    if (x > 89.0) return __builtin_inff();
+    const double kd = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(kd, -0x1.62e42fefa38p-1, x);
+    r = __builtin_fma(kd, -0x1.ef35793c7673p-45, r);
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, (int)kd);
+}
+
 struct f2 { float x, y; };
 __device__ __forceinline__ f2 df_mul_f(f2 a, float b)
 {

@@ -39,7 +39,7 @@ __device__ __forceinline__ void extend_pass(int pass, int i, int n, Arr &t, cons
 {
     const int ph = t[i].phoneme, s = t[i].start, e = t[i].end;
     if (s >= Tpad || ph >= C) return; // :719,:740,:760,:784
-    auto P = [&](int f) -> double { return (double)expf_u10(lp[(int64_t)f * ld + ph]); };
+    auto P = [&](int f) -> double { return (double)exp_cr(lp[(int64_t)f * ld + ph]); };
     const int d = e - s;
     if (pass == 1) { // :717-735
         int min_start = (int)((double)s - (double)d * 10.0);
@@ -86,7 +86,7 @@ __device__ __forceinline__ double seg_mean(const bfa_segment &g, const float *lp
 #pragma unroll
             for (int u = 0; u < U; ++u) x[u] = lp[(int64_t)min(f0 + u, ee - 1) * ld + g.phoneme];
 #pragma unroll
-            for (int u = 0; u < U; ++u) if (f0 + u < ee) acc += (double)expf_u10(x[u]);
+            for (int u = 0; u < U; ++u) if (f0 + u < ee) acc += (double)exp_cr(x[u]);
         }
         return (double)(float)(acc / (double)(ee - g.start));
     }

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void k_silprob(AlignArgs a)
             float v = 0.0f;
 #pragma unroll
             for (int k = 0; k < NK; ++k) if (k == sil_k) v = x[k];
-            if (j == sil_j && t < T) ps[t] = expf_u10(v);
+            if (j == sil_j && t < T) ps[t] = exp_cr(v);
         }
     }
 }

@@ -45,6 +45,8 @@ typedef struct {
 /* torch CPU (AVX512 dispatch) numerics, restated: Sleef expf/logf u10 and the
  * vectorised log_softmax reduction order. */
 float ora_expf_u10(float d);
+float ora_exp_cr(float x); /* restatement of torch.exp (float32 CPU): float64 exp rounded once */
+void ora_exp_cr_arr(const float *x, float *y, long n);
 float ora_logf_u10(float d);
 void ora_expf_u10_arr(const float *x, float *y, long n);
 void ora_logf_u10_arr(const float *x, float *y, long n);

@@ -72,6 +72,14 @@ def expf_u10(x):
     return y
 
 
+def exp_cr(x):
+    """the restatement of torch.exp (float32 CPU tensor): float64 exp rounded once to float32"""
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().ora_exp_cr_arr(_p(x), _p(y), ctypes.c_long(x.size))
+    return y
+
+
 def logf_u10(x):
     x = _f32(x)
     y = np.empty_like(x)

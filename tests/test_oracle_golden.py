@@ -157,3 +157,46 @@ def test_window_stitching_against_reference(ora):
         # the weights this build computes itself are the reference's
         w2 = torch.cos(torch.linspace(-np.pi / 2, np.pi / 2, F)).numpy()
         assert (w2.view(np.int32) == w.view(np.int32)).all()
+
+
+def oracle_level2(ora, logits, toks, seq_lens, spec, wav_lens, offsets, blank, softness):
+    """The oracle's stages chained like core.py:897-956 for one head: list[B] of (int rows [n,5], conf, start_ms, end_ms)."""
+    B = logits.shape[0]
+    lp = np.stack([ora.log_softmax_rows(logits[b]) for b in range(B)])
+    res = ora.decode_alignments(lp, toks, spec, seq_lens, ora.make_params(blank, 0))
+    assert (res["status"] == 0).all()
+    lists = ora.segments_as_lists(res)
+    out = []
+    for b in range(B):
+        segs = ora.ensure_target_coverage_default(lists[b], int(seq_lens[b]))
+        segs = ora.extend_soft_boundaries(lp[b], segs, int(softness))
+        rc, conf, st, en = ora.confidences(lp[b], segs)
+        assert rc == 0
+        segs = [(s[0], int(a), int(e), s[3]) for s, a, e in zip(segs, st, en)]
+        sm, em = ora.convert_to_ms(segs, int(spec[b]), float(offsets[b]), int(wav_lens[b]), 16000)
+        order = np.argsort(sm, kind="stable")
+        rows = np.array([[segs[k][0], segs[k][1], segs[k][2], segs[k][3], 0] for k in order], np.int32).reshape(-1, 5)
+        out.append((rows, conf[order], sm[order], em[order]))
+    return out
+
+
+def test_level2_large_fixture(ora):
+    """tests/golden/l2_large.npz (make_golden_l2.py): 64 utterances x 2 heads = 2670 reference 8-tuples, three
+    boundary_softness settings, flat and sharp posteriors, silences."""
+    z = np.load(os.path.join(os.path.dirname(GOLD), "l2_large.npz"))
+    n = exact = 0
+    for k in range(int(z["n_batches"])):
+        pre = f"b{k}_"
+        for head, logits, toks, blank in (("p", z[pre + "logits_class"], z[pre + "tokens"], 66),
+                                          ("g", z[pre + "logits_group"], z[pre + "group_tokens"], 16)):
+            got = oracle_level2(ora, logits, toks, z[pre + "seq_lens"], z[pre + "spectral_lens"], z[pre + "wav_lens"],
+                                z[pre + "offsets"], blank, int(z[pre + "softness"]))
+            for b, (rows, conf, sm, em) in enumerate(got):
+                gi, gf = z[f"{pre}{head}{b}_int"], z[f"{pre}{head}{b}_flt"]
+                np.testing.assert_array_equal(rows, gi, err_msg=f"batch {k} head {head} item {b}")
+                np.testing.assert_allclose(conf, gf[:, 0], atol=1.2e-7, rtol=0)
+                np.testing.assert_array_equal(sm, gf[:, 1])
+                np.testing.assert_array_equal(em, gf[:, 2])
+                n += len(conf)
+                exact += int((conf.view(np.int32) == gf[:, 0].copy().view(np.int32)).sum())
+    assert n == 2670 and exact > 0.9 * n, (n, exact)
