@@ -157,6 +157,7 @@ def _c1_aligner(d, lc, lg, **kw):
     T = d["T"]
     return PhonemeTimestampAligner(preset=None, device="cuda:0", posterior_fn=lambda w, wl: (lc, lg, [T] * lc.shape[0]),
                                    phonemizer=lambda text: dict(d["ts"]),
+                                   phoneme_id_to_group_id=dict(zip(d["tokens"], d["groups"])),
                                    phoneme_id_to_label={int(k): v for k, v in d["phoneme_labels"].items()},
                                    group_id_to_label={int(k): v for k, v in d["group_labels"].items()}, **kw)
 
@@ -217,6 +218,7 @@ def test_process_segments_error_behaviour_matches_reference(gpu_device):
         return PhonemeTimestampAligner(
             preset=None, device="cuda:0",
             posterior_fn=lambda w, wl: (lc2[:w.shape[0]], lg2[:w.shape[0]], [T] * w.shape[0]),
+            phoneme_id_to_group_id={i: 1 for i in range(66)},
             phonemizer=lambda text: dict(long_ts) if text == "long" else dict(d["ts"]))
     wav = torch.full((1, d["wav_samples"]), 0.05)
     al = make(1)
