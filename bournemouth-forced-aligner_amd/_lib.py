@@ -24,7 +24,7 @@ EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_l
 class BfaParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "blank_id", "silence_id", "silence_anchors", "ignore_noise", "truly_forced", "boost_targets",
-        "enforce_minimum", "simple", "max_blanks")] + [("reserved", ctypes.c_int32 * 3)]
+        "enforce_minimum", "simple", "max_blanks", "class_mask", "window_max_tokens", "window_max_frames")]
 
 
 class BfaSegment(ctypes.Structure):

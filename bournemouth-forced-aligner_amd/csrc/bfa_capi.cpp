@@ -62,7 +62,7 @@ struct Carve {
 bool segmented_possible(const bfa_params *p)
 {
     return !p->simple && p->silence_anchors > 0 && p->silence_id >= 0 &&
-           !((uint32_t)p->reserved[0] & (uint32_t)BFA_HINT_NO_SILENCE_TARGETS);
+           !((uint32_t)p->class_mask & (uint32_t)BFA_HINT_NO_SILENCE_TARGETS);
 }
 
 // shape-only bounds shared by bfa_workspace_bytes and bfa_align_batch
@@ -265,9 +265,9 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     a.p.ignore_noise = params->ignore_noise; a.p.truly_forced = params->truly_forced;
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = params->simple;
     a.p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
-    a.p.class_mask = (uint32_t)params->reserved[0]; a.p.win_mask = 0;
-    a.p.win_max_tokens = params->reserved[1] > 0 ? params->reserved[1] : bfa::WIN_MAX_TOKENS;
-    a.p.win_max_frames = params->reserved[2] > 0 ? params->reserved[2] : bfa::WIN_MAX_FRAMES;
+    a.p.class_mask = (uint32_t)params->class_mask; a.p.win_mask = 0;
+    a.p.win_max_tokens = params->window_max_tokens > 0 ? params->window_max_tokens : bfa::WIN_MAX_TOKENS;
+    a.p.win_max_frames = params->window_max_frames > 0 ? params->window_max_frames : bfa::WIN_MAX_FRAMES;
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
     // one wavefront per work item; surplus items are taken by the blocks' stride loops

@@ -139,7 +139,7 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 constexpr int WIN_MAX_FRAMES = 1536;
 // ... and every token costs the path at least one frame in a blank state; with a model that does not put noise between
 // phonemes that is about -15 per token after the boost, so past ~64 tokens the -1000 line is usually crossed too.
-// bfa_params.reserved[1] > 0 overrides this limit (e.g. a large value for posteriors known to be CTC-like).
+// bfa_params.window_max_tokens > 0 overrides this limit (e.g. a large value for posteriors known to be CTC-like).
 constexpr int WIN_MAX_TOKENS = 64;
 // Window backpointers as lane masks written by the scalar unit (1) or as per-lane packed dwords (0, kept for A/B):
 // with masks the consumer spends one v_cmp per code bit (the result lands in an SGPR pair and leaves through

@@ -121,9 +121,9 @@ class ViterbiDecoder:
         self._neg_inf = -1000.0
         self._ws = _Workspace()
         # K1's sliding-window variant is only tried up to this many tokens (None = the library's 64); raise it for
-        # posteriors that are known to keep path scores above the -1000 sentinel (bfa_params.reserved[1])
+        # posteriors that are known to keep path scores above the -1000 sentinel (bfa_params.window_max_tokens)
         self.window_max_tokens = None
-        self.window_max_frames = None   # likewise for the frame limit (bfa_params.reserved[2])
+        self.window_max_frames = None   # likewise for the frame limit (bfa_params.window_max_frames)
 
     def set_blank_id(self, blank_id):
         """forced_alignment.py:25-27"""
@@ -156,7 +156,7 @@ class ViterbiDecoder:
         return None
 
     _WIN_MAX_FRAMES = 1536  # bfa_types.hpp WIN_MAX_FRAMES
-    _WIN_MAX_TOKENS = 64    # bfa_types.hpp WIN_MAX_TOKENS (bfa_params.reserved[1] / `window_max_tokens` overrides)
+    _WIN_MAX_TOKENS = 64    # bfa_types.hpp WIN_MAX_TOKENS (bfa_params.window_max_tokens / `window_max_tokens` overrides)
 
     @classmethod
     def _win_class(cls, L, T=0):
@@ -177,7 +177,7 @@ class ViterbiDecoder:
 
     def class_mask_hint(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
                         boost_targets=True, enforce_minimum=True):
-        """Optional host-side hint for bfa_params.reserved[0]: the K1 kernel classes that occur in this batch,
+        """Optional host-side hint for bfa_params.class_mask: the K1 kernel classes that occur in this batch,
         from HOST copies of the lengths.  Bits 0-6: full-layout states-per-lane classes {2,3,4,6,8,12,16};
         bits 8-15: sliding-window classes Rw in {1,2,3,4,6,8} at bit 7+Rw (used for standard-mode DPs whose band is narrower than
         the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`).
@@ -261,9 +261,9 @@ class ViterbiDecoder:
         S_len = _as_i32(true_seqs_lens, dev)
         T_len = _as_i32(pred_lens, dev)
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
-        params.reserved[0] = int(class_mask)
-        params.reserved[1] = int(self.window_max_tokens or 0)
-        params.reserved[2] = int(self.window_max_frames or 0)
+        params.class_mask = int(class_mask)
+        params.window_max_tokens = int(self.window_max_tokens or 0)
+        params.window_max_frames = int(self.window_max_frames or 0)
         if seg_cap is None:
             seg_cap = Smax + 2 if self.ignore_noise else Tmax + 1
         L = _lib.lib()

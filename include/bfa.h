@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BFA_ABI_VERSION 1
+#define BFA_ABI_VERSION 2 /* v2: bfa_params hint fields named (same layout as v1's reserved[3]) */
 
 typedef struct bfa_context *bfa_handle;
 
@@ -59,7 +59,7 @@ typedef enum {
 #define BFA_ITEM_BAD_TOKEN 2   /* token id outside [0,C) : reference raises IndexError */
 #define BFA_ITEM_TOO_LARGE 3   /* CTC path longer than this build supports (8192 states = 2047 phonemes in one DP) */
 #define BFA_ITEM_SEG_OVERFLOW 4 /* more runs than seg_cap: frame outputs are valid, segments truncated */
-#define BFA_ITEM_BAD_HINT 5     /* the reserved[0] hint excluded what this utterance needs: BFA_HINT_NO_SILENCE_TARGETS
+#define BFA_ITEM_BAD_HINT 5     /* the class_mask hint excluded what this utterance needs: BFA_HINT_NO_SILENCE_TARGETS
                                    although the target contains silence_id, or a K1 class bit that is missing */
 
 #define BFA_HINT_NO_SILENCE_TARGETS (1 << 16)
@@ -82,17 +82,18 @@ typedef struct {
     int32_t enforce_minimum; /* default 1 : floor target columns at log(1e-8) */
     int32_t simple;          /* 1 = decode_alignments_simple semantics (forced_alignment.py:932-987) */
     int32_t max_blanks;      /* assort_frames(max_blanks=10) */
-    int32_t reserved[3];     /* [0] : optional host hint (0 = derive everything from the tensor shapes):
-                                bits 0-6  K1 full-layout states-per-lane classes {2,3,4,6,8,12,16} worth launching,
-                                bits 8-15 K1 sliding-window classes Rw in {1,2,3,4,6,8} (bit 7+Rw) worth launching,
-                                bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
-                                          silence-anchored planning kernels are not launched
-                                [1] : window token limit, 0 = default (64).  K1's sliding-window variant is exact only while
-                                the path score stays above the reference's -1000 sentinel; otherwise the utterance is
-                                redone with the full state layout.  Every token costs the path a frame in a blank state,
-                                so utterances with more tokens than this are not tried in the window at all.
-                                [2] : window frame limit, 0 = default (1536): likewise for long utterances (scores are sums
-                                of per-frame log-probabilities). */
+    /* ---- optional host hints (ABI v2 names; v1 carried them as reserved[0..2]).  0 = library default. ---- */
+    int32_t class_mask;        /* which K1 kernel classes are worth launching (0 = derive everything from the tensor
+                                  shapes): bits 0-6  full-layout states-per-lane classes {2,3,4,6,8,12,16},
+                                  bits 8-15 sliding-window classes Rw in {1,2,3,4,6,8} (bit 7+Rw),
+                                  bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
+                                            silence-anchored planning kernels are not launched.
+                                  A hint that excludes what an utterance needs is reported as BFA_ITEM_BAD_HINT. */
+    int32_t window_max_tokens; /* 0 = 64.  K1's sliding-window variant is exact only while the path score stays above
+                                  the reference's -1000 sentinel; otherwise the utterance is redone with the full state
+                                  layout.  Every token costs the path a frame in a blank state, so utterances with more
+                                  tokens than this are not tried in the window at all. */
+    int32_t window_max_frames; /* 0 = 1536: likewise for long utterances (scores are sums of per-frame log-probs). */
 } bfa_params;
 
 /* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),
