@@ -297,3 +297,54 @@ def test_window_stitching_against_reference_and_oracle(gpu_device):
             continue
         got = stich_window_predictions(torch.from_numpy(x).to(gpu_device), alen, F).cpu().numpy()
         assert (got.view(np.int32) == exp.view(np.int32)).all(), (B, NW, F, C)
+
+
+def test_integration_option_b_snippet(gold, gpu_device):
+    """INTEGRATION.md, Option B: the binding a maintainer of the reference would paste into forced_alignment.py is
+    extracted from the document and executed as it stands (pure ctypes, no import of this package), then reference
+    golden cases go through its AlignmentUtils.decode_alignments -- tuples, the too-short ValueError, a bad token."""
+    import re
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    sect = md[md.index("## Option B"):]
+    code = re.search(r"```python\n(.*?)```", sect, re.S).group(1)
+    driver = textwrap.dedent("""
+        import json, sys, numpy as np, torch
+        assert "bournemouth_forced_aligner_amd" not in sys.modules
+        gold = np.load(sys.argv[1])
+        meta = json.loads(str(gold["meta"]))
+        out = []
+        for i, m in enumerate(meta):
+            if m["anchors"] != 10 or not m["boost"] or not m["enforce"]:
+                continue
+            lp = torch.from_numpy(gold[f"c{i}_lp"]).cuda()
+            tk = torch.from_numpy(gold[f"c{i}_tok"].astype(np.int64))
+            au = AlignmentUtils(m["blank"], m["sil"], silence_anchors=m["anchors"], ignore_noise=m["ignore_noise"],
+                                truly_forced=m["truly_forced"])
+            args = (lp[None], tk[None] if tk.numel() else torch.zeros((1, 1), dtype=torch.int64), torch.tensor([m["T"]]),
+                    torch.tensor([m["S"]]))
+            try:
+                segs = au.decode_alignments(*args)[0]
+                ok = (not m["error"]) and np.array_equal(np.array(segs, np.int32).reshape(-1, 4), gold[f"c{i}_seg"])
+            except ValueError as e:
+                ok = bool(m["error"]) and "Audio too short to align" in str(e)
+            out.append(bool(ok))
+        try:
+            AlignmentUtils(66, 0).decode_alignments(torch.zeros(1, 50, 67).cuda(), torch.tensor([[3, 99, 4]]),
+                                                    torch.tensor([50]), torch.tensor([3]))
+            bad_token = False
+        except IndexError:
+            bad_token = True
+        print(json.dumps({"cases": len(out), "ok": sum(out), "bad_token": bad_token,
+                          "package_imported": "bournemouth_forced_aligner_amd" in sys.modules}))
+    """)
+    from bournemouth_forced_aligner_amd import _lib
+    env = dict(os.environ, BFA_HIP_LIBRARY=_lib.SO_PATH)
+    p = subprocess.run([sys.executable, "-c", code + "\n" + driver, GOLD], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["cases"] >= 3 and res["ok"] == res["cases"] and res["bad_token"] and not res["package_imported"], res
