@@ -18,13 +18,23 @@ MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
            "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
            "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
-           "bfa_prepare_emissions", "bfa_stitch_windows"]
+           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads"]
 
 
 class BfaParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "blank_id", "silence_id", "silence_anchors", "ignore_noise", "truly_forced", "boost_targets",
         "enforce_minimum", "simple", "max_blanks", "class_mask", "window_max_tokens", "window_max_frames")]
+
+
+class BfaHead(ctypes.Structure):
+    """include/bfa.h: bfa_head (one head of bfa_align_heads)"""
+    _fields_ = [("logits", ctypes.c_void_p), ("strideB", ctypes.c_int64), ("strideT", ctypes.c_int64),
+                ("C", ctypes.c_int32), ("Smax", ctypes.c_int32), ("tokens", ctypes.c_void_p), ("params", BfaParams),
+                ("out_row_stats", ctypes.c_void_p), ("out_frame_phoneme", ctypes.c_void_p),
+                ("out_frame_idx", ctypes.c_void_p), ("out_segs", ctypes.c_void_p), ("seg_cap", ctypes.c_int32),
+                ("out_seg_count", ctypes.c_void_p), ("out_status", ctypes.c_void_p), ("out_mode", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
 class BfaSegment(ctypes.Structure):
@@ -69,8 +79,9 @@ def lib():
                                   vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]
     L.bfa_prepare_emissions.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, ctypes.POINTER(BfaParams),
                                         vp, i64, i64, vp, sz, vp]
-    L.bfa_confidences.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]
-    L.bfa_postprocess.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]
+    L.bfa_confidences.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]
+    L.bfa_postprocess.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]
+    L.bfa_align_heads.argtypes = [vp, ctypes.POINTER(BfaHead), i32, i32, i32, vp, vp, vp]
     L.bfa_log_softmax.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
     L.bfa_stitch_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i64, i64, vp]
     L.bfa_profile_enable.argtypes = [vp, i32]

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .coverage import ensure_target_coverage
-from .forced_alignment import AlignmentUtils
+from .forced_alignment import AlignmentUtils, align_heads
 from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
 
 
@@ -158,9 +158,16 @@ class PhonemeTimestampAligner:
         return [self.phoneme_id_to_group_id.get(int(p), self.blank_group) for p in seq]
 
     # ---- one head: align -> coverage -> soft boundaries -> confidences, all on the device
-    def _head(self, utils, log_probs, seqs, seq_lens, spectral_lens):
-        res = utils.decode_alignments_device(log_probs, seqs, spectral_lens, seq_lens,
-                                             boost_targets=self.boost_targets, enforce_minimum=self.enforce_minimum)
+    def _head(self, utils, log_probs, seqs, seq_lens, spectral_lens, aligned=None):
+        """One head after the alignment: coverage -> soft boundaries -> confidences on the device.  `aligned` =
+        (AlignmentResult, row_stats) from the fused bfa_align_heads call, in which case `log_probs` holds the raw
+        logits; otherwise the head is aligned here from log-probs (the two-pass path)."""
+        if aligned is None:
+            res = utils.decode_alignments_device(log_probs, seqs, spectral_lens, seq_lens,
+                                                 boost_targets=self.boost_targets, enforce_minimum=self.enforce_minimum)
+            stats = None
+        else:
+            res, stats = aligned
         estimated = None
         if self.ensure_completeness:
             # rare-case repair over a handful of rows per utterance: host side (coverage.py), between the device
@@ -179,12 +186,13 @@ class PhonemeTimestampAligner:
             res.seg_count.copy_(torch.tensor([len(rs) for rs in rows], dtype=torch.int32))
             estimated = [[bool(r[4]) for r in rs] for rs in rows]
         postprocess_batch(log_probs, seq_lens, res.segs, res.seg_count, extend=self.extend_soft_boundaries,
-                          boundary_softness=self.boundary_softness)
-        conf, cstat = calculate_confidences_batch(log_probs, res.segs, res.seg_count)  # padded rows (core.py:936)
+                          boundary_softness=self.boundary_softness, row_stats=stats)
+        conf, cstat = calculate_confidences_batch(log_probs, res.segs, res.seg_count, row_stats=stats)  # padded rows (core.py:936)
         return res, conf, cstat, estimated
 
     def extract_timestamps_from_logits(self, logits_class, logits_group, spectral_lens, phoneme_sequences, wav_lens,
-                                       start_offset_times=0, group_sequences=None, do_groups=True, as_arrays=False):
+                                       start_offset_times=0, group_sequences=None, do_groups=True, as_arrays=False,
+                                       fused=True):
         """core.py:897-964 given the model's logits.  Returns list[B] of dicts with 'phoneme_timestamps' and
         'group_timestamps': lists of (id, start_frame, end_frame, target_seq_idx, is_estimated, confidence,
         start_ms, end_ms).  With `as_arrays` the same data as padded numpy arrays per head ({'rows' [B,cap,4],
@@ -214,11 +222,21 @@ class PhonemeTimestampAligner:
         else:
             gr = group_sequences.to(torch.int32)
         spec = [int(x) for x in spectral_lens]
-        lp_p = log_softmax(logits_class.to(dev))  # core.py:898-899
-        lp_g = log_softmax(logits_group.to(dev))
-        heads = [("phoneme_timestamps", self.alignment_utils_p, lp_p, ph)]
-        heads.append(("group_timestamps", self.alignment_utils_g, lp_g, gr))  # always runs (core.py:914)
-        pending = [(key, self._head(utils, lp, seqs, ph_seq_lens, spec)) for key, utils, lp, seqs in heads]
+        if fused and logits_class.shape[-1] >= 16 and logits_group.shape[-1] >= 16:
+            # raw logits of both heads in, log_softmax (core.py:898-899) inside the alignment
+            # kernels, both heads from one bfa_align_heads call; the later stages read (logits, row statistics)
+            xs = [logits_class.to(device=dev, dtype=torch.float32), logits_group.to(device=dev, dtype=torch.float32)]
+            us = [self.alignment_utils_p, self.alignment_utils_g]
+            aligned = align_heads(us, xs, [ph, gr], spec, ph_seq_lens, boost_targets=self.boost_targets,
+                                  enforce_minimum=self.enforce_minimum)
+            pending = [(key, self._head(u, x, sq, ph_seq_lens, spec, aligned=al))
+                       for key, u, x, sq, al in zip(("phoneme_timestamps", "group_timestamps"), us, xs, [ph, gr], aligned)]
+        else:
+            lp_p = log_softmax(logits_class.to(dev))  # core.py:898-899
+            lp_g = log_softmax(logits_group.to(dev))
+            heads = [("phoneme_timestamps", self.alignment_utils_p, lp_p, ph)]
+            heads.append(("group_timestamps", self.alignment_utils_g, lp_g, gr))  # always runs (core.py:914)
+            pending = [(key, self._head(utils, lp, seqs, ph_seq_lens, spec)) for key, utils, lp, seqs in heads]
         out = [dict() for _ in range(B)]
         arrays = {}
         for key, (res, conf, cstat, estimated) in pending:

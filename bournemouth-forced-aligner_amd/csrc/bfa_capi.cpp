@@ -22,7 +22,7 @@ extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out
                                       int C, void *stream);
 extern "C" int bfa_launch_stitch(const float *win, int B, int NW, int F, int C, const float *weights, int total_frames,
                                  float *out, int64_t oB, int64_t oT, void *stream);
-extern "C" int bfa_launch_postprocess(const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                                       const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count,
                                       int extend, double th1, double th2, void *stream);
 
@@ -40,6 +40,9 @@ struct bfa_context {
     hipEvent_t aux_done[NAUX] = {};
     hipEvent_t forked = nullptr;
     int naux = 0;
+    // bfa_align_heads: heads after the first are enqueued on this stream (forked from / joined into the caller's)
+    hipStream_t head_stream = nullptr;
+    hipEvent_t head_fork = nullptr, head_join = nullptr;
 };
 
 namespace {
@@ -172,6 +175,14 @@ int bfa_create(bfa_handle *out, int device)
                  hipEventCreateWithFlags(&h->aux_done[k], hipEventDisableTiming) == hipSuccess;
             if (ok) h->naux = k + 1;
         }
+        const char *serial = getenv("BFA_HEADS_SERIAL"); // (measurement switch: heads one after the other)
+        if (!(serial && serial[0] == '1') && hipStreamCreateWithFlags(&h->head_stream, hipStreamNonBlocking) == hipSuccess) {
+            if (hipEventCreateWithFlags(&h->head_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->head_join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(h->head_stream);
+                h->head_stream = nullptr;
+            }
+        }
         (void)hipSetDevice(prev);
     }
     *out = h;
@@ -211,6 +222,9 @@ int bfa_destroy(bfa_handle h)
             if (h->aux_done[k]) (void)hipEventDestroy(h->aux_done[k]);
         }
         if (h->forked) (void)hipEventDestroy(h->forked);
+        if (h->head_stream) (void)hipStreamDestroy(h->head_stream);
+        if (h->head_fork) (void)hipEventDestroy(h->head_fork);
+        if (h->head_join) (void)hipEventDestroy(h->head_join);
     }
     delete h;
     return BFA_OK;
@@ -227,7 +241,9 @@ size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p
     return carve_all(c, B, Tmax, Smax, p, l, nullptr, true) + 256;
 }
 
-int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+} // extern "C"
+
+static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                     const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
                     const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
                     bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
@@ -258,7 +274,14 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     const size_t need = carve_all(c, B, Tmax, Smax, params, l, &a, need_frames) + (aligned - basep);
     if (need > workspace_bytes) return fail(h, BFA_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
 
-    a.logp = logp; a.strideB = strideB; a.strideT = strideT;
+    a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT;
+    if (row_stats) {
+        if (C < 16) return fail(h, BFA_ERR_UNSUPPORTED, "raw-logit input needs C >= 16 (vectorised softmax order)");
+        // rows no kernel prepares (silence fills, frames beyond an utterance, items without a DP) keep this NaN and get
+        // their statistics from the first sparse reader that needs them (bfa_math.hpp: row_stats_on_demand)
+        if (hipMemsetAsync(row_stats, 0xFF, (size_t)B * (size_t)Tmax * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return fail(h, BFA_ERR_LAUNCH, "memset of row_stats failed");
+    }
     a.B = B; a.Tmax = Tmax; a.C = C; a.Smax = Smax;
     a.T_len = T_len; a.tokens = tokens; a.S_len = S_len;
     a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = params->silence_anchors;
@@ -284,6 +307,49 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
                                     h->forked ? h->naux : 0);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
+}
+
+
+extern "C" {
+
+int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
+                    const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
+                    bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
+                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return align_impl(h, logp, nullptr, strideB, strideT, B, Tmax, C, T_len, tokens, S_len, Smax, params,
+                      out_frame_phoneme, out_frame_idx, out_segs, seg_cap, out_seg_count, out_status, out_mode, workspace,
+                      workspace_bytes, stream);
+}
+
+int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int Tmax, const int32_t *T_len,
+                    const int32_t *S_len, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (!heads || n_heads <= 0 || n_heads > 8) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad head list");
+    for (int k = 0; k < n_heads; ++k)
+        if (!heads[k].logits || !heads[k].out_row_stats) return fail(h, BFA_ERR_INVALID_ARGUMENT, "head without logits / out_row_stats");
+    const bool side = n_heads > 1 && h->head_stream != nullptr;
+    if (side) {
+        (void)hipEventRecord(h->head_fork, (hipStream_t)stream);
+        (void)hipStreamWaitEvent(h->head_stream, h->head_fork, 0);
+    }
+    int rc = BFA_OK;
+    // the later heads first, on the side stream; head 0 (the wide phoneme head) last on the caller's stream: its kernels
+    // are the long ones, the others fill in beside them
+    for (int k = n_heads - 1; k >= 0 && rc == BFA_OK; --k) {
+        const bfa_head &hd = heads[k];
+        void *st = (side && k > 0) ? (void *)h->head_stream : stream;
+        rc = align_impl(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, T_len, hd.tokens, S_len,
+                        hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
+                        hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st);
+    }
+    if (side) {
+        (void)hipEventRecord(h->head_join, h->head_stream);
+        (void)hipStreamWaitEvent((hipStream_t)stream, h->head_join, 0);
+    }
+    return rc;
 }
 
 int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
@@ -317,7 +383,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
     return BFA_OK;
 }
 
-int bfa_confidences(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                     const int32_t *T_rows, const bfa_segment *segs, int seg_cap, const int32_t *seg_count,
                     float *out_conf, int32_t *out_item_status, void *stream)
 {
@@ -325,14 +391,14 @@ int bfa_confidences(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     if (!logp || !segs || !seg_count || !out_conf) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
     bfa::ConfArgs a;
-    a.logp = logp; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.T_rows = T_rows;
+    a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.T_rows = T_rows;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.conf = out_conf; a.status = out_item_status;
     const int rc = bfa_launch_conf(&a, stream);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }
 
-int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                     const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int extend,
                     int boundary_softness, void *stream)
 {
@@ -342,7 +408,7 @@ int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t st
     if (seg_cap > 4096) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 4096 in bfa_postprocess");
     // core.py:699-701 : python `10.0 ** -n` is libm pow on doubles
     const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)boundary_softness);
-    const int rc = bfa_launch_postprocess(logp, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, extend,
+    const int rc = bfa_launch_postprocess(logp, row_stats, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, extend,
                                           th1, th2, stream);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;

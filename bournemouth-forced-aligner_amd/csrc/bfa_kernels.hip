@@ -232,13 +232,15 @@ __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
 // =================================================================================================
 constexpr int CONF_SERIAL_CAP = 2048;
 
+template <bool RAW>
 __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
 {
     __shared__ float mval[CONF_SERIAL_CAP];
     __shared__ uint8_t mflag[CONF_SERIAL_CAP];
     const int lane = threadIdx.x & 63;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const float *lp = a.logp + (int64_t)b * a.strideB;
+        const LpView<RAW> lp{a.logp + (int64_t)b * a.strideB, a.strideT,
+                             RAW ? a.row_stats + 2 * (int64_t)b * a.Tmax : nullptr, a.C};
         const bfa_segment *sg = a.segs + (int64_t)b * a.seg_cap;
         float *cf = a.conf + (int64_t)b * a.seg_cap;
         int T = a.T_rows ? a.T_rows[b] : a.Tmax;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
                 const int ph = sg[i].phoneme;
                 const int s = max(0, sg[i].start), e = min(T, sg[i].end); // :86-87
                 if (s >= T || ph < 0 || ph >= a.C) { bad = 1; cf[i] = 0.0f; continue; } // IndexError at :89
-                float c = exp_cr(lp[(int64_t)s * a.strideT + ph]);
+                float c = exp_cr(lp.at(s, ph));
                 if (s < e) {
                     const float half = c / 2.0f; // :95 (a fresh tensor: stays constant)
                     int good = 1;
@@ -273,8 +275,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
                     constexpr int U = 8;
                     for (int f0 = s + 1; f0 < e; f0 += U) {
                         float x[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) x[u] = lp[(int64_t)min(f0 + u, e - 1) * a.strideT + ph];
+                        lp.template at_n<U>(f0, e - 1, ph, x);
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             if (f0 + u < e) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
                 auto prob = [&](int f, int ph, int upto) -> float {
                     for (int k = upto; k >= 0; --k)
                         if (mflag[k] && sg[k].phoneme == ph && max(0, sg[k].start) == f) return mval[k];
-                    return exp_cr(lp[(int64_t)f * a.strideT + ph]);
+                    return exp_cr(lp.at(f, ph));
                 };
                 for (int i = 0; i < n; ++i) {
                     const int ph = sg[i].phoneme;
@@ -461,7 +462,8 @@ extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream_)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(k_conf, dim3(args->B < 65536 ? args->B : 65536), dim3(64), 0, stream, *args);
+    if (args->row_stats) hipLaunchKernelGGL(k_conf<true>, dim3(args->B < 65536 ? args->B : 65536), dim3(64), 0, stream, *args);
+    else hipLaunchKernelGGL(k_conf<false>, dim3(args->B < 65536 ? args->B : 65536), dim3(64), 0, stream, *args);
     return (int)hipGetLastError();
 }
 

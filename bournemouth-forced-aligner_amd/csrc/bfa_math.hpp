@@ -154,4 +154,71 @@ __device__ __forceinline__ float row16_max(float v)
     return v;
 }
 
+// ---- sparse readers of the log-prob matrix (confidences, soft boundaries) -------------------------------------------
+// RAW = false: the matrix is stored.  RAW = true: `lp` holds the raw logits and `st` the per-row (maximum, log-sum) pairs
+// of their log_softmax, written by K1 for every row it prepared: log_prob = (x - max) - logsum, torch's two float32
+// subtractions.  Rows K1 never prepared (silence fills, frames beyond the utterance, proportional / empty items) still
+// hold the NaN the call initialised the buffer with; the reader then computes that row's statistics itself -- the same
+// sixteen-accumulator order, one lane, slow but rare -- and leaves them for the next reader.
+__device__ __noinline__ float2 row_stats_on_demand(const float *row, int C, float *slot)
+{
+    float mx = row[0];
+    for (int c = 1; c < C; ++c) mx = __builtin_fmaxf(mx, row[c]);
+    float acc[16];
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float e = expf_u10(row[c] - mx);
+        acc[c & 15] = (c < 16) ? e : (acc[c & 15] + e);
+    }
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] + acc[j + 8];   // xor 8
+    for (int j = 0; j < 4; ++j) acc[j] = acc[j] + acc[j + 4];   // xor 4
+    const float ls = logf_u10((acc[0] + acc[2]) + (acc[1] + acc[3])); // xor 2, xor 1
+    const float2 r = make_float2(mx, ls);
+    *(float2 *)slot = r;
+    return r;
+}
+
+template <bool RAW>
+struct LpView {
+    const float *lp; // row 0 of the utterance
+    int64_t ld;
+    float *st;       // RAW: row statistics of the utterance ([Tmax] pairs)
+    int C;
+    __device__ __forceinline__ float at(int f, int c) const
+    {
+        const float x = lp[(int64_t)f * ld + c];
+        if (!RAW) return x;
+        float2 ms = *(const float2 *)(st + 2 * (int64_t)f);
+        if (ms.x != ms.x || ms.y != ms.y) ms = row_stats_on_demand(lp + (int64_t)f * ld, C, st + 2 * (int64_t)f);
+        return (x - ms.x) - ms.y;
+    }
+    // U elements of column c, frames f0 .. f0+U-1 clamped to `fmax`: every load (values and statistics) is issued before
+    // anything is looked at, so the 2U of them are in flight together (one element per row: latency is the whole cost)
+    template <int U>
+    __device__ __forceinline__ void at_n(int f0, int fmax, int c, float (&out)[U]) const
+    {
+        float2 ms[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int f = min(f0 + u, fmax);
+            out[u] = lp[(int64_t)f * ld + c];
+            if (RAW) ms[u] = *(const float2 *)(st + 2 * (int64_t)f);
+        }
+        if (RAW) {
+            bool missing = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) missing = missing || (ms[u].x != ms[u].x) || (ms[u].y != ms[u].y);
+            if (missing) { // (unrolled: a dynamic index would push ms[] into scratch memory)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int f = min(f0 + u, fmax);
+                    if (ms[u].x != ms[u].x || ms[u].y != ms[u].y) ms[u] = row_stats_on_demand(lp + (int64_t)f * ld, C, st + 2 * (int64_t)f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) out[u] = (out[u] - ms[u].x) - ms[u].y;
+        }
+    }
+};
+
 } // namespace bfa

@@ -22,6 +22,7 @@ __device__ __forceinline__ void post_sync()
 
 struct PostArgs {
     const float *logp;
+    float *row_stats; // != nullptr: logp is raw logits (AlignArgs::row_stats)
     int64_t strideB, strideT;
     int32_t B, Tmax, C;
     const int32_t *S_len;
@@ -33,13 +34,13 @@ struct PostArgs {
 };
 
 // the four passes for tuple i on an array `t` (LDS or global)
-template <typename Arr>
-__device__ __forceinline__ void extend_pass(int pass, int i, int n, Arr &t, const float *lp, int64_t ld, int Tpad, int C,
+template <typename Arr, bool RAW>
+__device__ __forceinline__ void extend_pass(int pass, int i, int n, Arr &t, const LpView<RAW> &lp, int Tpad, int C,
                                             double th1, double th2, const double *mean)
 {
     const int ph = t[i].phoneme, s = t[i].start, e = t[i].end;
     if (s >= Tpad || ph >= C) return; // :719,:740,:760,:784
-    auto P = [&](int f) -> double { return (double)exp_cr(lp[(int64_t)f * ld + ph]); };
+    auto P = [&](int f) -> double { return (double)exp_cr(lp.at(f, ph)); };
     const int d = e - s;
     if (pass == 1) { // :717-735
         int min_start = (int)((double)s - (double)d * 10.0);
@@ -74,7 +75,8 @@ __device__ __forceinline__ void extend_pass(int pass, int i, int n, Arr &t, cons
     }
 }
 
-__device__ __forceinline__ double seg_mean(const bfa_segment &g, const float *lp, int64_t ld, int Tpad, int C)
+template <bool RAW>
+__device__ __forceinline__ double seg_mean(const bfa_segment &g, const LpView<RAW> &lp, int Tpad, int C)
 {
     // :709-714 ; float32 mean of the column slice (accumulated in double, rounded once)
     if (g.start < Tpad && g.phoneme < C && g.start < g.end) {
@@ -83,8 +85,7 @@ __device__ __forceinline__ double seg_mean(const bfa_segment &g, const float *lp
         constexpr int U = 8; // independent (clamped) loads in flight: one element per 268-byte row
         for (int f0 = g.start; f0 < ee; f0 += U) {
             float x[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = lp[(int64_t)min(f0 + u, ee - 1) * ld + g.phoneme];
+            lp.template at_n<U>(f0, ee - 1, g.phoneme, x);
 #pragma unroll
             for (int u = 0; u < U; ++u) if (f0 + u < ee) acc += (double)exp_cr(x[u]);
         }
@@ -93,6 +94,7 @@ __device__ __forceinline__ double seg_mean(const bfa_segment &g, const float *lp
     return 0.001;
 }
 
+template <bool RAW>
 __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
     const double th1 = a.th1, th2 = a.th2;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         bfa_segment *sg = a.segs + (int64_t)b * a.seg_cap;
-        const float *lp = a.logp + (int64_t)b * a.strideB;
+        const LpView<RAW> lp{a.logp + (int64_t)b * a.strideB, a.strideT,
+                             RAW ? a.row_stats + 2 * (int64_t)b * a.Tmax : nullptr, a.C};
         int n = a.seg_count[b];
         if (n > a.seg_cap) n = a.seg_cap;
         const int S = a.S_len[b];
@@ -133,10 +136,10 @@ __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
             post_sync();
         }
         if (a.extend) {
-            for (int i = lane; i < m; i += 64) smean[i] = seg_mean(st[i], lp, a.strideT, a.Tmax, a.C);
+            for (int i = lane; i < m; i += 64) smean[i] = seg_mean(st[i], lp, a.Tmax, a.C);
             post_sync();
             for (int pass = 1; pass <= 4; ++pass) {
-                for (int i = lane; i < m; i += 64) extend_pass(pass, i, m, st, lp, a.strideT, a.Tmax, a.C, th1, th2, smean);
+                for (int i = lane; i < m; i += 64) extend_pass(pass, i, m, st, lp, a.Tmax, a.C, th1, th2, smean);
                 post_sync();
             }
         }
@@ -148,15 +151,16 @@ __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
 
 } // namespace bfa
 
-extern "C" int bfa_launch_postprocess(const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                                       const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count,
                                       int extend, double th1, double th2, void *stream_)
 {
     using namespace bfa;
     PostArgs a;
-    a.logp = logp; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.S_len = S_len;
+    a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.S_len = S_len;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.extend = extend; a.th1 = th1; a.th2 = th2;
     const size_t lds = (size_t)seg_cap * (8 + sizeof(bfa_segment));
-    hipLaunchKernelGGL(k_postprocess, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
+    if (row_stats) hipLaunchKernelGGL(k_postprocess<true>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(k_postprocess<false>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }

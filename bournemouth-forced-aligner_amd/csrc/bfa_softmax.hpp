@@ -31,7 +31,7 @@ __device__ __forceinline__ RowLane make_rowlane(int nk, int j, int C, int blank,
 }
 
 template <int NK>
-__device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid)
+__device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid, float *mx_out = nullptr, float *ls_out = nullptr)
 {
     float mx = x[0];
 #pragma unroll
@@ -49,6 +49,7 @@ __device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid)
     const float ls = logf_u10(row16_butterfly_add(acc));
 #pragma unroll
     for (int k = 0; k < NK; ++k) x[k] = x[k] - ls;
+    if (mx_out) { *mx_out = mx; *ls_out = ls; }
 }
 
 // silence anchoring (forced_alignment.py:543-561): `cnt` times { x[blank] += 5 ; x = log_softmax(x) }.

@@ -60,6 +60,11 @@ struct DevParams {
 struct AlignArgs {
     const float *logp;
     int64_t strideB, strideT;
+    // != nullptr: `logp` holds RAW LOGITS (core.py:897); every kernel that prepares rows first applies
+    // F.log_softmax(dim=-1) (core.py:898-899) and K1 writes that row's (maximum, log-sum) here, [B, Tmax] pairs, so
+    // that the later sparse readers (confidences, soft boundaries) reconstitute log_prob = (x - max) - logsum with the
+    // very same two float32 subtractions (no separate log-softmax pass over the logits)
+    float *row_stats;
     int32_t B, Tmax, C, Smax;
     const int32_t *T_len, *tokens, *S_len;
     DevParams p;
@@ -87,6 +92,7 @@ struct AlignArgs {
 
 struct ConfArgs {
     const float *logp;
+    float *row_stats; // != nullptr: logp is raw logits, see AlignArgs::row_stats (rows without statistics get them here)
     int64_t strideB, strideT;
     int32_t B, Tmax, C;
     const int32_t *T_rows;

@@ -228,10 +228,10 @@ class ViterbiDecoder:
             mask |= _lib.HINT_NO_SILENCE_TARGETS  # the silence-anchored planning kernels are not launched
         return mask
 
-    def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
-                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
-        """Whole-batch device call (bfa_align_batch).  Returns an AlignmentResult of device tensors; nothing
-        is synchronised or copied to the host here."""
+    def _prepare_call(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
+                      anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
+        """Everything one bfa_align_batch / bfa_head needs: device views of the inputs, the parameter block (with the
+        class hint derived from host-resident lengths), the output tensors and the workspace."""
         if log_probs.dim() != 3:
             raise ValueError("log_probs must be [B, T, C]")
         dev = _device_of(log_probs)
@@ -267,26 +267,42 @@ class ViterbiDecoder:
         if seg_cap is None:
             seg_cap = Smax + 2 if self.ignore_noise else Tmax + 1
         L = _lib.lib()
-        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
         nbytes = L.bfa_workspace_bytes(B, Tmax, Smax, C, ctypes.byref(params))
-        ws = self._ws.get(nbytes, dev)
-        segs = torch.empty((B, seg_cap, 4), dtype=torch.int32, device=dev)
-        seg_count = torch.empty((B,), dtype=torch.int32, device=dev)
-        status = torch.empty((B,), dtype=torch.int32, device=dev)
-        mode = torch.empty((B,), dtype=torch.int32, device=dev)
-        fph = torch.empty((B, Tmax), dtype=torch.int32, device=dev)
-        fidx = torch.empty((B, Tmax), dtype=torch.int32, device=dev)
+        c = dict(dev=dev, lp=lp, B=B, Tmax=Tmax, C=C, toks=toks, Smax=Smax, S_len=S_len, T_len=T_len, params=params,
+                 seg_cap=seg_cap, ws=self._ws.get(nbytes, dev),
+                 segs=torch.empty((B, seg_cap, 4), dtype=torch.int32, device=dev),
+                 seg_count=torch.empty((B,), dtype=torch.int32, device=dev),
+                 status=torch.empty((B,), dtype=torch.int32, device=dev),
+                 mode=torch.empty((B,), dtype=torch.int32, device=dev),
+                 fph=torch.empty((B, Tmax), dtype=torch.int32, device=dev),
+                 fidx=torch.empty((B, Tmax), dtype=torch.int32, device=dev))
+        return c
+
+    @staticmethod
+    def _result(c):
+        res = AlignmentResult(c["segs"], c["seg_count"], c["status"], c["mode"], c["fph"], c["fidx"], c["T_len"], c["S_len"])
+        res._keepalive = (c["lp"], c["toks"], c["ws"])
+        return res
+
+    def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
+                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
+        """Whole-batch device call (bfa_align_batch).  Returns an AlignmentResult of device tensors; nothing
+        is synchronised or copied to the host here."""
+        c = self._prepare_call(log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets, enforce_minimum,
+                               anchor_pauses, simple, seg_cap, max_blanks, class_mask)
+        dev, lp, T_len = c["dev"], c["lp"], c["T_len"]
+        L = _lib.lib()
+        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = L.bfa_align_batch(h, lp.data_ptr(), lp.stride(0), lp.stride(1), B, Tmax, C,
-                                   T_len.data_ptr() if T_len is not None else None, toks.data_ptr(),
-                                   S_len.data_ptr(), Smax, ctypes.byref(params), fph.data_ptr(), fidx.data_ptr(),
-                                   segs.data_ptr(), seg_cap, seg_count.data_ptr(), status.data_ptr(),
-                                   mode.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            rc = L.bfa_align_batch(h, lp.data_ptr(), lp.stride(0), lp.stride(1), c["B"], c["Tmax"], c["C"],
+                                   T_len.data_ptr() if T_len is not None else None, c["toks"].data_ptr(),
+                                   c["S_len"].data_ptr(), c["Smax"], ctypes.byref(c["params"]), c["fph"].data_ptr(),
+                                   c["fidx"].data_ptr(), c["segs"].data_ptr(), c["seg_cap"], c["seg_count"].data_ptr(),
+                                   c["status"].data_ptr(), c["mode"].data_ptr(), c["ws"].data_ptr(), c["ws"].numel(),
+                                   stream)
         _lib.check(rc, h, "bfa_align_batch")
-        res = AlignmentResult(segs, seg_count, status, mode, fph, fidx, T_len, S_len)
-        res._keepalive = (lp, toks, ws)
-        return res
+        return self._result(c)
 
     def prepare_emissions(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True):
         """The reference's `modified_log_probs` (forced_alignment.py:121-129: _boost_target_phonemes then
@@ -411,3 +427,42 @@ class AlignmentUtils:
                                                enforce_minimum=False, anchor_pauses=False, simple=True)
         res.raise_for_status()
         return res.to_lists()
+
+
+def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
+                seg_cap=None):
+    """core.py:897-922 from the model's RAW logits for every head in ONE library call (bfa_align_heads): the
+    log_softmax of core.py:898-899 is fused into the alignment kernels, no log-prob matrix is written.  `utils_list` are
+    the heads' AlignmentUtils (phoneme head first), `logits_list` / `seqs_list` their [B,T,C] logits and [B,S] targets.
+    Returns [(AlignmentResult, row_stats [B,T,2]) per head]; later stages take (logits, row_stats) in place of log-probs
+    (calculate_confidences_batch / postprocess_batch `row_stats=`)."""
+    calls = []
+    for au, lg, sq in zip(utils_list, logits_list, seqs_list):
+        vd = au.viterbi_decoder
+        c = vd._prepare_call(lg, sq, pred_lens, true_seqs_lens, boost_targets, enforce_minimum,
+                             au.silence_anchors > 0, False, seg_cap, 10, 0)
+        c["stats"] = torch.empty((c["B"], c["Tmax"], 2), dtype=torch.float32, device=c["dev"])
+        calls.append(c)
+    c0 = calls[0]
+    for c in calls[1:]:
+        if (c["B"], c["Tmax"]) != (c0["B"], c0["Tmax"]) or c["dev"] != c0["dev"]:
+            raise ValueError("all heads must share batch size, frame count and device")
+    heads = (_lib.BfaHead * len(calls))()
+    for k, c in enumerate(calls):
+        hd = heads[k]
+        hd.logits, hd.strideB, hd.strideT = c["lp"].data_ptr(), c["lp"].stride(0), c["lp"].stride(1)
+        hd.C, hd.Smax, hd.tokens, hd.params = c["C"], c["Smax"], c["toks"].data_ptr(), c["params"]
+        hd.out_row_stats = c["stats"].data_ptr()
+        hd.out_frame_phoneme, hd.out_frame_idx = c["fph"].data_ptr(), c["fidx"].data_ptr()
+        hd.out_segs, hd.seg_cap = c["segs"].data_ptr(), c["seg_cap"]
+        hd.out_seg_count, hd.out_status, hd.out_mode = c["seg_count"].data_ptr(), c["status"].data_ptr(), c["mode"].data_ptr()
+        hd.workspace, hd.workspace_bytes = c["ws"].data_ptr(), c["ws"].numel()
+    dev = c0["dev"]
+    L = _lib.lib()
+    h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+    T_len = c0["T_len"]
+    with torch.cuda.device(dev):
+        rc = L.bfa_align_heads(h, heads, len(calls), c0["B"], c0["Tmax"], T_len.data_ptr() if T_len is not None else None,
+                               c0["S_len"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, h, "bfa_align_heads")
+    return [(ViterbiDecoder._result(c), c["stats"]) for c in calls]

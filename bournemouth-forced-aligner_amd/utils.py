@@ -12,9 +12,10 @@ from . import _lib
 from .forced_alignment import _as_i32, _device_of
 
 
-def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None):
+def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None, row_stats=None):
     """Batch form: log_probs [B,T,C] (device), segs int32 [B,seg_cap,4], seg_count int32 [B].
-    Returns (conf float32 [B,seg_cap], status int32 [B]) as device tensors; no synchronisation."""
+    Returns (conf float32 [B,seg_cap], status int32 [B]) as device tensors; no synchronisation.
+    With `row_stats` ([B,T,2] from bfa_align_heads) `log_probs` holds the RAW LOGITS instead."""
     dev = _device_of(log_probs)
     lp = log_probs.to(device=dev, dtype=torch.float32)
     if lp.stride(2) != 1:
@@ -30,7 +31,8 @@ def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None):
     h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
-        rc = L.bfa_confidences(h, lp.data_ptr(), lp.stride(0), lp.stride(1), B, Tmax, C,
+        rc = L.bfa_confidences(h, lp.data_ptr(), row_stats.data_ptr() if row_stats is not None else None,
+                               lp.stride(0), lp.stride(1), B, Tmax, C,
                                T_rows.data_ptr() if T_rows is not None else None, segs.data_ptr(), seg_cap,
                                seg_count.data_ptr(), conf.data_ptr(), status.data_ptr(), stream)
     _lib.check(rc, h, "bfa_confidences")
@@ -120,10 +122,11 @@ def log_softmax(logits):
     return out
 
 
-def postprocess_batch(log_probs, S_len, segs, seg_count, extend=True, boundary_softness=3):
+def postprocess_batch(log_probs, S_len, segs, seg_count, extend=True, boundary_softness=3, row_stats=None):
     """core.py:925-931 on the device, in place on `segs` / `seg_count`: ensure_target_coverage with
     ensure_completeness=False (drops target_idx -1 / >= S, stable sort by start) and, if `extend`,
-    extend_soft_boundaries_func over the padded rows (bfa_postprocess)."""
+    extend_soft_boundaries_func over the padded rows (bfa_postprocess).  With `row_stats` ([B,T,2] from
+    bfa_align_heads) `log_probs` holds the RAW LOGITS instead."""
     dev = _device_of(log_probs)
     lp = log_probs.to(device=dev, dtype=torch.float32)
     if lp.stride(2) != 1:
@@ -135,7 +138,8 @@ def postprocess_batch(log_probs, S_len, segs, seg_count, extend=True, boundary_s
     L = _lib.lib()
     h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
     with torch.cuda.device(dev):
-        rc = L.bfa_postprocess(h, lp.data_ptr(), lp.stride(0), lp.stride(1), B, Tmax, C, S_len.data_ptr(),
+        rc = L.bfa_postprocess(h, lp.data_ptr(), row_stats.data_ptr() if row_stats is not None else None,
+                               lp.stride(0), lp.stride(1), B, Tmax, C, S_len.data_ptr(),
                                segs.data_ptr(), segs.shape[1], seg_count.data_ptr(), int(bool(extend)),
                                int(boundary_softness), torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, h, "bfa_postprocess")

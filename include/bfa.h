@@ -150,10 +150,13 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
  * utils._calculate_confidences (utils.py:70-113) for a whole batch, including the reference's
  * in-place aliasing of probs[start, phoneme].  logp is the ORIGINAL (un-boosted) matrix; T_rows[b]
  * is log_probs.shape[0] of item b as the reference passes it (the padded Tmax, core.py:936).
+ *   row_stats  NULL: logp holds log-probabilities.  Otherwise logp holds the RAW LOGITS the matrix was made from and
+ *              row_stats the [B,Tmax,2] row statistics bfa_align_heads wrote for them (see there; rows the
+ *              alignment never prepared get their statistics filled in here, so the buffer is read-write).
  *   segs [B,seg_cap] ; seg_count [B] ; out_conf [B,seg_cap] float32 ;
  *   out_item_status [B] (BFA_ITEM_BAD_TOKEN where the reference would raise IndexError)
  */
-int bfa_confidences(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                     const int32_t *T_rows, const bfa_segment *segs, int seg_cap, const int32_t *seg_count,
                     float *out_conf, int32_t *out_item_status, void *stream);
 
@@ -161,11 +164,41 @@ int bfa_confidences(bfa_handle h, const float *logp, int64_t strideB, int64_t st
  * Post-DP boundary stages of extract_timestamps_from_segment_batch (core.py:925-931), in place on
  * segs/seg_count: ensure_target_coverage with ensure_completeness=False (drop target_idx -1 / >= S,
  * stable sort by start; core.py:488-513,660) then, if extend != 0, extend_soft_boundaries_func
- * (core.py:682-809) over the padded Tmax rows.
+ * (core.py:682-809) over the padded Tmax rows.  row_stats as in bfa_confidences.
  */
-int bfa_postprocess(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                     const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int extend,
                     int boundary_softness, void *stream);
+
+/*
+ * The front of extract_timestamps_from_segment_batch (core.py:897-922) for all heads of the model in ONE call: raw
+ * logits in, F.log_softmax(dim=2) (core.py:898-899) fused into the alignment kernels' row preparation, the phoneme
+ * head (C = 67) and the group head (C = 17) aligned from the same call.  No log-prob
+ * matrix is ever written: K1 normalises each 16-row block in registers (bit-identical to torch's CPU log_softmax),
+ * goes on to boost / floor / DP with it, and leaves the row's (maximum, log-sum) pair in out_row_stats, from which
+ * bfa_confidences / bfa_postprocess reconstitute the few log-probs they touch as (x - max) - logsum -- the same two
+ * float32 subtractions.  Heads after the first run on a stream of the handle, forked from and joined into `stream`.
+ * T_len / S_len are shared by the heads (core.py:874-876); everything else is per head.
+ */
+typedef struct {
+    const float *logits;        /* [B,Tmax,C] raw model outputs, element (b,t,c) at b*strideB + t*strideT + c */
+    int64_t strideB, strideT;
+    int32_t C;
+    int32_t Smax;
+    const int32_t *tokens;      /* [B,Smax] target ids of this head */
+    bfa_params params;          /* blank / silence ids of this head, flags, hints */
+    float *out_row_stats;       /* [B,Tmax,2] float32: (row maximum, log of the row's exp-sum) of log_softmax */
+    int32_t *out_frame_phoneme; /* [B,Tmax] or NULL (both or neither) */
+    int32_t *out_frame_idx;
+    bfa_segment *out_segs;      /* [B,seg_cap] */
+    int32_t seg_cap;
+    int32_t *out_seg_count, *out_status, *out_mode; /* [B] ; out_mode may be NULL */
+    void *workspace;            /* bfa_workspace_bytes(B, Tmax, Smax, C, &params); one per head */
+    size_t workspace_bytes;
+} bfa_head;
+
+int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int Tmax, const int32_t *T_len,
+                    const int32_t *S_len, void *stream);
 
 /*
  * Measurement hooks (bench.py): with on = n >= 1, every n-th bfa_align_batch call brackets its K1 launches

@@ -348,3 +348,45 @@ def test_integration_option_b_snippet(gold, gpu_device):
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["cases"] >= 3 and res["ok"] == res["cases"] and res["bad_token"] and not res["package_imported"], res
+
+
+def test_fused_front_end_equals_two_pass(gpu_device):
+    """raw logits -> bfa_align_heads (log_softmax inside K1's row preparation, row statistics for the
+    sparse readers, both heads from one call) against the two-pass path (bfa_log_softmax, then one bfa_align_batch per
+    head): every output array bitwise equal -- rows, counts, confidence bit patterns, ms -- on a mixed batch (silences
+    -> segmented mode with anchored pieces, flat posteriors -> sentinel reruns, stride-1 / proportional utterances,
+    one path beyond 1024 states)."""
+    import cases
+    from bournemouth_forced_aligner_amd import PhonemeTimestampAligner
+    rng = np.random.default_rng(77)
+    shapes = [(300, 40, 9.0, 0.0), (500, 70, 6.0, 0.2), (260, 60, 2.0, 0.0), (120, 100, 5.0, 0.0), (90, 90, 5.0, 0.1),
+              (1400, 300, 7.0, 0.0), (700, 20, 1.0, 0.15), (64, 3, 8.0, 0.3), (1100, 120, 8.0, 0.1), (33, 30, 3.0, 0.0)]
+    Tmax = max(s[0] for s in shapes)
+    B = len(shapes)
+    lc = np.zeros((B, Tmax, 67), np.float32)
+    lg = rng.normal(0, 1, (B, Tmax, 17)).astype(np.float32)
+    lc[:, :, 66] = 5.0
+    seqs, spec, wl = [], [], []
+    for b, (T, S, peak, silr) in enumerate(shapes):
+        lp, tk, planted = cases.planted_case(rng, T, S, C=67, peak=peak, sil_rate=silr, sil_len=(10, 30), repeat_rate=0.05)
+        lc[b, :T] = lp * np.float32(1.7) + np.float32(rng.normal(0, 3))  # logits: scaled and shifted log-probs
+        pg = np.where(planted == 66, 16, np.where(planted == 0, 0, 1 + planted % 15))
+        lg[b, np.arange(T), pg] += np.float32(peak * 0.7)
+        seqs.append([int(x) for x in tk])
+        spec.append(T)
+        wl.append(T * 320)
+    gmap = {p: (0 if p == 0 else 1 + p % 15) for p in range(66)}
+    al = PhonemeTimestampAligner(preset=None, device="cuda:0", phoneme_id_to_group_id=gmap)
+    a = al.extract_timestamps_from_logits(torch.from_numpy(lc), torch.from_numpy(lg), spec, seqs, wl, start_offset_times=0.5,
+                                          as_arrays=True, fused=True)
+    b2 = al.extract_timestamps_from_logits(torch.from_numpy(lc), torch.from_numpy(lg), spec, seqs, wl, start_offset_times=0.5,
+                                           as_arrays=True, fused=False)
+    for key in ("phoneme_timestamps", "group_timestamps"):
+        assert (a[key]["count"] == b2[key]["count"]).all() and a[key]["count"].sum() > 300
+        for f in ("rows", "is_estimated", "start_ms", "end_ms"):
+            for i in range(B):
+                n = int(a[key]["count"][i])
+                np.testing.assert_array_equal(a[key][f][i, :n], b2[key][f][i, :n], err_msg=f"{key} {f} item {i}")
+        for i in range(B):
+            n = int(a[key]["count"][i])
+            assert (a[key]["confidence"][i, :n].view(np.int32) == b2[key]["confidence"][i, :n].view(np.int32)).all()

@@ -14,6 +14,7 @@ import bench  # noqa: E402
 from bournemouth_forced_aligner_amd import PhonemeTimestampAligner  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+FUSED = (sys.argv[2] != "0") if len(sys.argv) > 2 else True  # 1: bfa_align_heads from raw logits, 0: log_softmax pass + two calls
 dev = torch.device("cuda", 0)
 T, S = 1000, 40
 lp, toks = bench.synth_batch(B, T, S, 67, 1003, dev)
@@ -27,15 +28,15 @@ al = PhonemeTimestampAligner(device="cuda:0", phoneme_id_to_group_id=gmap)
 seqs = toks.cpu().tolist()
 spec = [T] * B
 wl = [T * 268] * B
-for as_arrays in (False, True):
+for as_arrays in ((True,) if len(sys.argv) > 2 else (False, True)):
     for it in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         kw = {"as_arrays": True} if as_arrays else {}
-        out = al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, **kw)
+        out = al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, fused=FUSED, **kw)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print(f"B={B} as_arrays={as_arrays}: {dt * 1e3:.1f} ms per call ({B * T / dt / 1e6:.1f} M frames/s through the API)")
+    print(f"B={B} fused={FUSED} as_arrays={as_arrays}: {dt * 1e3:.1f} ms per call ({B * T / dt / 1e6:.1f} M frames/s through the API)")
     if hasattr(al, "last_device_ms"):
         print("   device passes:", {k: round(v, 3) for k, v in al.last_device_ms.items()})
 
@@ -45,7 +46,7 @@ if os.environ.get("BFA_PROFILE_HOST"):
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(5):
-        al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, as_arrays=True)
+        al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, as_arrays=True, fused=FUSED)
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
