@@ -13,6 +13,7 @@
 // per-step address and shift arithmetic folds into a handful of instructions.
 #include <hip/hip_runtime.h>
 
+#include "bfa_assort.hpp"
 #include "bfa_math.hpp"
 #include "bfa_types.hpp"
 
@@ -25,6 +26,90 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// assort_frames (forced_alignment.py:777-834) DURING the walk (utterances that are one DP item): the walk visits the
+// chunks from the last frame down, so the runs come out in reverse.  A frame that ends a run (its (phoneme, index) pair
+// differs from the frame above it, or it is the last frame) tells where the run ABOVE it starts; that run's end is the
+// next run end above, or -- past the top of the chunk -- the end carried over from the chunks already walked.  Tuples
+// go to the back of the utterance's segment array (slot cap-1-k for the k-th tuple found) and are moved to the front
+// by finish(); if there are more than seg_cap of them the forward pass (assort_utterance) redoes the utterance, which
+// also sets the overflow status exactly as the K3a kernel does.
+struct RleRev {
+    bfa_segment *out;
+    int cap, count;
+    int c_end;          // end (exclusive) of the run that reaches down into the chunk being walked
+    int n_ph, n_id;     // pair of the lowest frame walked so far
+    int blank, ignore_noise, max_blanks, Tr;
+    bool overflow;
+    __device__ __forceinline__ void init(const AlignArgs &a, int b, int Tr_)
+    {
+        out = a.segs + (int64_t)b * a.seg_cap; cap = a.seg_cap; count = 0; c_end = Tr_; n_ph = 0; n_id = 0;
+        blank = a.p.blank; ignore_noise = a.p.ignore_noise; max_blanks = a.p.max_blanks; Tr = Tr_; overflow = false;
+    }
+    __device__ __forceinline__ bool emits(int ph, int len) const
+    {
+        return (ph == blank) ? (!ignore_noise && len > max_blanks) : true; // :819-831
+    }
+    // frames [t0, t0+n) of the utterance, lane l <-> frame t0+l, (ph, id) valid for l < n
+    __device__ __forceinline__ void chunk(int ph, int id, int t0, int n, int lane)
+    {
+        int uph = __builtin_amdgcn_update_dpp(0, ph, 0x130, 0xf, 0xf, true); // wave_shl:1, lane l <- lane l+1
+        int uid = __builtin_amdgcn_update_dpp(0, id, 0x130, 0xf, 0xf, true);
+        if (lane == n - 1) { uph = n_ph; uid = n_id; }
+        const int t = t0 + lane;
+        const bool in = lane < n;
+        const bool is_end = in && ((t == Tr - 1) || ph != uph || id != uid);
+        const unsigned long long E = __ballot(is_end);
+        // the run above an end frame: [t+1, next end above) with the pair of frame t+1; none above the last frame
+        const unsigned long long above = (lane >= 63) ? 0ull : (E >> (lane + 1));
+        const int r_end = above ? (t + 1 + __builtin_ctzll(above) + 1) : c_end;
+        const bool has_run = is_end && (t + 1 < Tr);
+        const bool emit = has_run && emits(uph, r_end - (t + 1));
+        const unsigned long long em = __ballot(emit);
+        if (emit) {
+            const unsigned long long higher = (lane >= 63) ? 0ull : (em >> (lane + 1));
+            const int k = count + __builtin_popcountll(higher);
+            if (k < cap) { bfa_segment sg; sg.phoneme = uph; sg.start = t + 1; sg.end = r_end; sg.target_idx = uid; out[cap - 1 - k] = sg; }
+        }
+        count += __builtin_popcountll(em);
+        if (E) c_end = t0 + __builtin_ctzll(E) + 1;
+        n_ph = __builtin_amdgcn_readlane(ph, 0);
+        n_id = __builtin_amdgcn_readlane(id, 0);
+    }
+    // after frame 0 has been walked: the run that starts at frame 0, then the tuples move to the front
+    __device__ __forceinline__ void finish(const AlignArgs &a, int b, int lane)
+    {
+        if (Tr > 0 && emits(n_ph, c_end)) {
+            if (lane == 0 && count < cap) { bfa_segment sg; sg.phoneme = n_ph; sg.start = 0; sg.end = c_end; sg.target_idx = n_id; out[cap - 1 - count] = sg; }
+            count += 1;
+        }
+        if (count > cap) { // more runs than seg_cap: the forward pass keeps the FIRST seg_cap and reports the overflow
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            assort_utterance<1>(a, b, lane);
+            return;
+        }
+        // out[cap-count .. cap) holds the tuples last-to-first: tuple j (front order) sits at cap-count+ (count-1-j) ...
+        // written as slot cap-1-k for the k-th found = the k-th from the END, i.e. front index j = count-1-k lives at
+        // cap-1-k = cap-count+j: already in front order inside the back block; move the block down by cap-count.
+        const int shift = cap - count;
+        if (shift > 0) {
+            for (int j0 = 0; j0 < count; j0 += 64) { // ascending: a batch's sources lie above everything written so far
+                const int j = j0 + lane;
+                bfa_segment sg;
+                if (j < count) sg = out[shift + j];
+                __builtin_amdgcn_wave_barrier();
+                if (j < count) out[j] = sg;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) {
+            a.seg_count[b] = count;
+            if (a.mode) { const int md = a.umode[b]; a.mode[b] = md < 0 ? (-1 - md) : md; }
+        }
+    }
+};
+
 // Backpointer layouts (written by DpCore / DpCoreW in bfa_dp3.inc and k_dp in bfa_dp.inc):
 //   full   : rows of 4 frames, W = ceil(R/4) dwords per lane and row, lanes < nl = ceil(L/R); dword w of lane l
 //            holds slots 4w..4w+3 (Rsub of them), pair (frame f, slot r) at bits 2*(4*Rsub-1-(f*Rsub+(r&3))).
@@ -32,7 +117,7 @@ __device__ __forceinline__ void wave_sync_lds()
 //            lane l, slot r of a row holds state base[row] + l*R + r, pair (f, r) at bits 2*(FPW*R-1-(f*R+r)).
 // code = (A<<1)|B with A = (c0 < best), B = (c1 < best): k = A ? (B ? 2 : 1) : 0 = max(code,1) - 1.
 template <int R, bool WIN>
-__device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, uint32_t *sbp, int32_t *stok, int lane)
+__device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, uint32_t *sbp, int32_t *stok, int lane, RleRev &rle, bool do_rle)
 {
     constexpr int W = WIN ? 1 : (R + 3) / 4;
     constexpr int FPW = WIN ? (R == 1 ? 16 : R == 2 ? 8 : 4) : 4;
@@ -160,10 +245,10 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
             if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap (:692)
             t_hi = t0 + jl - 1;
         }
+        int ph = p.blank, id = -1;
         if (mine) {
             const int o = t - it.pad_left; // :447-448 trim the boundary padding
             if (o >= 0 && o < it.nout) {
-                int ph = p.blank, id = -1;
                 if (my_state >= 1) {
                     const int q = ((my_state - 1) * inv_stride) >> 16;
                     if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = stok[q]; id = it.tok0 + q; }
@@ -172,6 +257,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
                 oid[it.out0 + o] = id;
             }
         }
+        if (do_rle) rle.chunk(ph, id, t0, t1 - t0, lane); // (one-item utterances: pad_left = 0, nout = Ts)
     };
     // the register buffers keep their roles (no copies, which would wait for the loads in flight)
     static_assert(NPRE == 3, "the unrolled group below is written for three buffers");
@@ -191,7 +277,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
 // B = c1 < best; k = A ? (B ? 2 : 1) : 0).  Lane = frame: a lane keeps its frame's 2R masks in registers (loaded ahead,
 // coalesced), so a walk step is select / shift / ballot with no memory access.
 template <int R, bool WIN, int NC = 1>
-__device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &it, uint32_t *sbp, int32_t *stok, int lane)
+__device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &it, uint32_t *sbp, int32_t *stok, int lane, RleRev &rle, bool do_rle)
 {
     constexpr int FPW = (R == 1) ? 16 : (R == 2) ? 8 : 4;
     constexpr int FSH = (FPW == 16) ? 4 : (FPW == 8) ? 3 : 2;
@@ -293,10 +379,10 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
             todo &= (1ull << jl) - 1ull;
         }
         if (STAGE) fetch(buf, bufb, c - NPRE); // behind the walk: its loads overlap the stores below and the next chunk
+        int ph = p.blank, id = -1;
         if (lane < n) {
             const int o = t - it.pad_left; // :447-448 trim the boundary padding
             if (o >= 0 && o < it.nout) {
-                int ph = p.blank, id = -1;
                 if (my_state >= 1) {
                     const int q = ((my_state - 1) * inv_stride) >> 16;
                     if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = (q < 1024) ? stok[q] : tok[q]; id = it.tok0 + q; }
@@ -305,6 +391,7 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
                 oid[it.out0 + o] = id;
             }
         }
+        if (do_rle) rle.chunk(ph, id, t0, n, lane);
     };
     int cg = nchunks - 1;
     if (NPRE == 3) {
@@ -329,7 +416,7 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
 // Paths of more than 1024 states (k_dp_big): backpointers row-major, [frame][ng = ceil(L/16)] dwords, dword g =
 // states 16g..16g+15, 2 bits each.  Same ballot-jump walk; every lane keeps the dword of its frame for the current
 // state's group and reloads it when the walk enters another group (every <= 16 moves).
-__device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it, int32_t *stok, int lane)
+__device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it, int32_t *stok, int lane, RleRev &rle, bool do_rle)
 {
     const DevParams &p = a.p;
     const int b = it.utt;
@@ -366,10 +453,10 @@ __device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it
             t_hi = t0 + jl - 1;
             if ((s >> 4) != g) { g = s >> 4; wd = mine ? bp[(int64_t)t * ng + g] : 0u; }
         }
+        int ph = p.blank, id = -1;
         if (mine) {
             const int o = t - it.pad_left;
             if (o >= 0 && o < it.nout) {
-                int ph = p.blank, id = -1;
                 if (my_state >= 1) {
                     const int q = (my_state - 1) / it.stride;
                     if ((my_state - 1) - q * it.stride == 0 && q < it.nt) { ph = tok[q]; id = it.tok0 + q; }
@@ -378,36 +465,76 @@ __device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it
                 oid[it.out0 + o] = id;
             }
         }
+        if (do_rle) rle.chunk(ph, id, t0, t1 - t0, lane);
     }
     (void)stok;
 }
 
-// (4 waves per SIMD: a 4096-utterance batch is resident at once)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_backtrace(AlignArgs a)
+// Which items a launch takes (AlignArgs::k2_sel): with one K1 kernel per class running side by side, the full-layout
+// classes are walked right behind their own K1 kernel on its stream (the walks of the short classes then overlap the
+// DPs of the long ones); window items wait for the sentinel reruns, which follow the join.
+//   K2_ALL          every item (legacy order: one launch after all K1 kernels)
+//   K2_FULL + R     full-layout DPs of class R that a K1 kernel has finished
+//   K2_BIG          paths of more than 1024 states
+//   K2_REST         everything the two above never take: non-DP items, window items, rerun items, items no K1 kernel took
+__device__ __forceinline__ bool k2_selected(int sel, const Item &it)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t sbp[18 * 64]; // one chunk: <= 1024 dwords (dword layouts) / 9 qwords per lane (staged masks)
-    __shared__ int32_t stok[1024];    // the item's tokens (nt <= L <= 1024)
+    if (sel == K2_ALL) return true;
+    const bool plain_full = it.kind == ITEM_DP && it.win == 0 && it.final_state != FINAL_NOT_COMPUTED;
+    if (sel == K2_REST) return !plain_full;
+    if (!plain_full) return false;
+    if (sel == K2_BIG) return it.L > 1024;
+    return it.L <= 1024 && r_class_for_L(it.L) == (sel - K2_FULL);
+}
+
+__device__ __forceinline__ void wave_sync_global()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// Two builds of the walk kernel share the items: the NARROW one (window Rw <= 4, full layout R <= 4: the classes a big
+// batch of short utterances lands in) keeps 4 waves per SIMD so that a 4096-utterance batch is resident at once; the
+// WIDE one (Rw = 6 / 8, R >= 6, paths beyond 1024 states: long utterances, few of them) may use the whole register
+// file -- its staged walks hold two 64-frame chunks of 2R lane masks per lane, and with the 128-register budget they
+// spilled into scratch memory inside the step loop (0.65 ms for the R = 8 class of the mixed-length shard).
+__device__ __forceinline__ bool k2_is_wide(const Item &it)
+{
+    if (it.kind != ITEM_DP) return false;
+    if (it.win > 0) return it.win > 4;
+    return it.L > 1024 || r_class_for_L(it.L) >= 6;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void backtrace_body(const AlignArgs &a, uint32_t *sbp, int32_t *stok)
+{
     const int lane = threadIdx.x & 63;
     const DevParams &p = a.p;
     const int n_items = a.counters[0];
+    // the walk is one short dependent chain per step; beside the K1 kernels of other classes (whose DP waves run at
+    // raised priority) it would otherwise only get the issue slots they leave
+    __builtin_amdgcn_s_setprio(3);
+    const bool fused = a.k2_fused_rle != 0; // every utterance is ONE item: this kernel also produces its tuples (K3a)
     for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
         const Item it = a.items[i];
+        if (!k2_selected(a.k2_sel, it)) continue;
+        if (k2_is_wide(it) != WIDE) continue;
         const int b = it.utt;
         int32_t *oph = a.frame_ph + (int64_t)b * a.Tmax;
         int32_t *oid = a.frame_idx + (int64_t)b * a.Tmax;
         const int32_t *tok = a.tokens + (int64_t)b * a.Smax + it.tok0;
+        bool filled = false;
         if (it.kind == ITEM_FILL_BLANK) {
             for (int t = lane; t < it.nout; t += 64) { oph[it.out0 + t] = p.blank; oid[it.out0 + t] = -1; }
-            continue;
-        }
-        if (it.kind == ITEM_FILL_PROP) { // forced_alignment.py:170-172
+            filled = true;
+        } else if (it.kind == ITEM_FILL_PROP) { // forced_alignment.py:170-172
             for (int t = lane; t < it.nout; t += 64) {
                 const int fi = (int)(((int64_t)t * it.nt) / it.nout);
                 oph[it.out0 + t] = tok[fi]; oid[it.out0 + t] = it.tok0 + fi;
             }
-            continue;
-        }
-        if (it.kind == ITEM_FILL_SIL) { // forced_alignment.py:382-397
+            filled = true;
+        } else if (it.kind == ITEM_FILL_SIL) { // forced_alignment.py:382-397
             // frames per SIL token of the WHOLE silence segment (it.Ts frames); only the first it.nout of them are
             // written when the concatenation is cut off at T (:465-467)
             const double fps = (it.nt > 0) ? (double)it.Ts / (double)it.nt : 0.0;
@@ -425,48 +552,89 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 }
                 oph[it.out0 + t] = p.sil; oid[it.out0 + t] = id;
             }
+            filled = true;
+        } else if (it.kind != ITEM_DP) {
             continue;
-        }
-        if (it.kind != ITEM_DP) continue;
-        if (it.final_state < 0) { // no K1 kernel took this item: its class was missing from the caller's class hint
+        } else if (it.final_state < 0) { // no K1 kernel took this item: its class was missing from the caller's class hint
             for (int t = lane; t < it.nout; t += 64) { oph[it.out0 + t] = p.blank; oid[it.out0 + t] = -1; }
             if (lane == 0 && a.status[b] == BFA_ITEM_OK) a.status[b] = BFA_ITEM_BAD_HINT;
+            filled = true;
+        }
+        if (filled) {
+            if (fused) { wave_sync_global(); assort_utterance<1>(a, b, lane); } // the forward pass over what was just written
             continue;
         }
+        RleRev rle;
+        rle.init(a, b, it.Ts);
+        const bool do_rle = fused;
         if (it.win > 0) {
-            switch (it.win) {
-            case 1: if (WIN_SSTORE) walk_item_mask<1, true>(a, it, sbp, stok, lane); else walk_item<1, true>(a, it, sbp, stok, lane); break;
-            case 2: if (WIN_SSTORE) walk_item_mask<2, true>(a, it, sbp, stok, lane); else walk_item<2, true>(a, it, sbp, stok, lane); break;
-            case 3: if (WIN_SSTORE) walk_item_mask<3, true>(a, it, sbp, stok, lane); else walk_item<3, true>(a, it, sbp, stok, lane); break;
-            case 4: if (WIN_SSTORE) walk_item_mask<4, true>(a, it, sbp, stok, lane); else walk_item<4, true>(a, it, sbp, stok, lane); break;
-            case 6: if (WIN_SSTORE) walk_item_mask<6, true>(a, it, sbp, stok, lane); break;
-            default: if (WIN_SSTORE) walk_item_mask<8, true>(a, it, sbp, stok, lane); break;
+            if constexpr (!WIDE) {
+                switch (it.win) {
+                case 1: if (WIN_SSTORE) walk_item_mask<1, true>(a, it, sbp, stok, lane, rle, do_rle); else walk_item<1, true>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 2: if (WIN_SSTORE) walk_item_mask<2, true>(a, it, sbp, stok, lane, rle, do_rle); else walk_item<2, true>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 3: if (WIN_SSTORE) walk_item_mask<3, true>(a, it, sbp, stok, lane, rle, do_rle); else walk_item<3, true>(a, it, sbp, stok, lane, rle, do_rle); break;
+                default: if (WIN_SSTORE) walk_item_mask<4, true>(a, it, sbp, stok, lane, rle, do_rle); else walk_item<4, true>(a, it, sbp, stok, lane, rle, do_rle); break;
+                }
+            } else {
+                if (it.win == 6) { if (WIN_SSTORE) walk_item_mask<6, true>(a, it, sbp, stok, lane, rle, do_rle); }
+                else { if (WIN_SSTORE) walk_item_mask<8, true>(a, it, sbp, stok, lane, rle, do_rle); }
             }
         } else {
-            if (it.split == 2) { // K1 split the DP over two consumer waves: per-frame lane masks (bfa_dp5.inc)
-                switch (r_class_for_L(it.L)) {
-                case 4: walk_item_mask<4, false, 2>(a, it, sbp, stok, lane); break;
-                case 6: walk_item_mask<6, false, 2>(a, it, sbp, stok, lane); break;
-                default: walk_item_mask<8, false, 2>(a, it, sbp, stok, lane); break; // (R = 12, 16 are not split: 2R masks per frame would not fit K2's registers)
+            if constexpr (!WIDE) {
+                if (it.split == 2) walk_item_mask<4, false, 2>(a, it, sbp, stok, lane, rle, do_rle); // (BFA_SPLIT_R4 builds)
+                else switch (r_class_for_L(it.L)) {
+                case 2: walk_item<2, false>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 3: walk_item<3, false>(a, it, sbp, stok, lane, rle, do_rle); break;
+                default: walk_item<4, false>(a, it, sbp, stok, lane, rle, do_rle); break;
                 }
-            } else
-            switch (r_class_for_L(it.L)) {
-            case 2: walk_item<2, false>(a, it, sbp, stok, lane); break;
-            case 3: walk_item<3, false>(a, it, sbp, stok, lane); break;
-            case 4: walk_item<4, false>(a, it, sbp, stok, lane); break;
-            case 6: walk_item<6, false>(a, it, sbp, stok, lane); break;
-            case 8: walk_item<8, false>(a, it, sbp, stok, lane); break;
-            case 12: walk_item<12, false>(a, it, sbp, stok, lane); break;
-            case 16: walk_item<16, false>(a, it, sbp, stok, lane); break;
-            default: walk_item_big(a, it, stok, lane); break;
+            } else if (it.split == 2) { // K1 split the DP over two consumer waves: per-frame lane masks (bfa_dp5.inc)
+                if (r_class_for_L(it.L) == 6) walk_item_mask<6, false, 2>(a, it, sbp, stok, lane, rle, do_rle);
+                else walk_item_mask<8, false, 2>(a, it, sbp, stok, lane, rle, do_rle);
+            } else {
+                switch (it.L > 1024 ? 0 : r_class_for_L(it.L)) {
+                case 6: walk_item<6, false>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 8: walk_item<8, false>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 12: walk_item<12, false>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 16: walk_item<16, false>(a, it, sbp, stok, lane, rle, do_rle); break;
+                default: walk_item_big(a, it, stok, lane, rle, do_rle); break;
+                }
             }
+        }
+        if (fused) {
+            rle.finish(a, b, lane);
+            for (int t = it.Ts + lane; t < a.Tmax; t += 64) { oph[t] = p.blank; oid[t] = -1; } // beyond the utterance
         }
     }
 }
 
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_backtrace(AlignArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sbp[18 * 64]; // one chunk: <= 1024 dwords (dword layouts) / 9 qwords per lane (staged masks)
+    __shared__ int32_t stok[1024];    // the item's tokens (nt <= L <= 1024)
+    backtrace_body<false>(a, sbp, stok);
+}
+
+__global__ __launch_bounds__(64) void k_backtrace_wide(AlignArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t sbp[18 * 64];
+    __shared__ int32_t stok[1024];
+    backtrace_body<true>(a, sbp, stok);
+}
+
 } // namespace bfa
 
-extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream)
+// `wide` : bit 0 = the narrow kernel may find items, bit 1 = the wide one may (see k2_is_wide)
+extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream, int wide)
 {
-    hipLaunchKernelGGL(bfa::k_backtrace, dim3(grid), dim3(64), 0, stream, *args);
+    if (wide & 1) hipLaunchKernelGGL(bfa::k_backtrace, dim3(grid), dim3(64), 0, stream, *args);
+    if (wide & 2) hipLaunchKernelGGL(bfa::k_backtrace_wide, dim3(grid), dim3(64), 0, stream, *args);
+}
+
+// one selection of items (see k2_selected); `fused` = also produce the tuples (no K3a launch follows)
+extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, int fused, int grid, hipStream_t stream, int wide)
+{
+    bfa::AlignArgs a = *args;
+    a.k2_sel = sel;
+    a.k2_fused_rle = fused;
+    bfa_launch_backtrace(&a, grid, stream, wide);
 }

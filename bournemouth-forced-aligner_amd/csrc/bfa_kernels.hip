@@ -12,6 +12,7 @@
 // No MFMA anywhere: this is a memory-streaming scan with ~13 float ops per CTC state per frame.
 #include <hip/hip_runtime.h>
 
+#include "bfa_assort.hpp"
 #include "bfa_softmax.hpp"
 
 #pragma clang fp contract(off)
@@ -151,80 +152,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const DevParams &p = a.p;
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        int32_t *ph = a.frame_ph + (int64_t)b * a.Tmax;
-        int32_t *ix = a.frame_idx + (int64_t)b * a.Tmax;
-        const int T = a.uT[b];
-        const int st = a.status[b];
-        const bool none = (st != BFA_ITEM_OK) || (a.uS[b] == 0 && !p.simple);
-        const int Tr = none ? 0 : T; // frames that take part in the run-length encoding
-        for (int t = Tr + lane; t < a.Tmax; t += 64) { ph[t] = p.blank; ix[t] = -1; }
-        bfa_segment *out = a.segs + (int64_t)b * a.seg_cap;
-        int count = 0;
-        int run_start = 0, run_ph = 0, run_ix = 0; // the open run (wave-uniform)
-        // the framewise arrays are read eight 64-frame slices at a time: the slices do not depend on each other,
-        // only the run bookkeeping does, and one load round trip per slice would be the whole kernel time
-        constexpr int U = 8;
-        for (int base0 = 0; base0 < Tr; base0 += 64 * U) {
-            int vph[U], vix[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = base0 + 64 * u + lane;
-                vph[u] = (t < Tr) ? ph[t] : 0;
-                vix[u] = (t < Tr) ? ix[t] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int base = base0 + 64 * u;
-                if (base >= Tr) break; // wave-uniform
-                const int t = base + lane;
-                const bool in = t < Tr;
-                const int cph = vph[u], cix = vix[u];
-                int pph = __builtin_amdgcn_update_dpp(0, cph, DPP_WAVE_SHR1, 0xf, 0xf, true); // lane l <- lane l-1
-                int pix = __builtin_amdgcn_update_dpp(0, cix, DPP_WAVE_SHR1, 0xf, 0xf, true);
-                if (lane == 0) { pph = run_ph; pix = run_ix; }
-                const bool is_start = in && (t == 0 || cph != pph || cix != pix); // :798-801
-                const unsigned long long m = __ballot(is_start);
-                // a start at t>0 closes the run that began at the previous start (shuffles stay convergent)
-                const unsigned long long below = m & ((1ull << lane) - 1ull);
-                const int src = below ? (63 - __builtin_clzll(below)) : 0;
-                const int ps = below ? (base + src) : run_start;
-                const int pp = pph, pi = pix; // every frame of the closing run carries its (phoneme, index)
-                const bool closes = is_start && t > 0;
-                bool emit = false;
-                if (closes) {
-                    const int len = t - ps;
-                    if (pp == p.blank) emit = (!p.ignore_noise) && (len > p.max_blanks); // :819-827
-                    else emit = true;                                                    // :830-831
-                }
-                const unsigned long long em = __ballot(emit);
-                if (emit) {
-                    const int slot = count + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-                    if (slot < a.seg_cap) { bfa_segment sg; sg.phoneme = pp; sg.start = ps; sg.end = t; sg.target_idx = pi; out[slot] = sg; }
-                }
-                count += __builtin_popcountll(em);
-                const int last = m ? (63 - __builtin_clzll(m)) : 0;
-                const int lph = __builtin_amdgcn_readlane(cph, last), lix = __builtin_amdgcn_readlane(cix, last);
-                if (m) { run_start = base + last; run_ph = lph; run_ix = lix; }
-            }
-        }
-        if (Tr > 0) { // close the final run
-            const int len = Tr - run_start;
-            bool emit;
-            if (run_ph == p.blank) emit = (!p.ignore_noise) && (len > p.max_blanks);
-            else emit = true;
-            if (emit) {
-                if (lane == 0 && count < a.seg_cap) { bfa_segment sg; sg.phoneme = run_ph; sg.start = run_start; sg.end = Tr; sg.target_idx = run_ix; out[count] = sg; }
-                count += 1;
-            }
-        }
-        if (lane == 0) {
-            if (count > a.seg_cap) { a.seg_count[b] = a.seg_cap; if (st == BFA_ITEM_OK) a.status[b] = BFA_ITEM_SEG_OVERFLOW; }
-            else a.seg_count[b] = count;
-            if (a.mode) { const int md = a.umode[b]; a.mode[b] = md < 0 ? (-1 - md) : md; }
-        }
-    }
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) assort_utterance<8>(a, b, lane);
 }
 
 // =================================================================================================
@@ -378,7 +306,8 @@ extern "C" void bfa_launch_dp_redo_nk8(const bfa::AlignArgs *args, unsigned clas
 extern "C" void bfa_launch_dp_big_nk2(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_big_nk5(const bfa::AlignArgs *args, int grid, hipStream_t stream);
 extern "C" void bfa_launch_dp_big_nk8(const bfa::AlignArgs *args, int grid, hipStream_t stream);
-extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream);
+extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream, int wide);
+extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, int fused, int grid, hipStream_t stream, int wide);
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
@@ -406,6 +335,12 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     }
     a.p.win_mask = wmask;
     mask |= wmask << 8;
+    // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
+    // class right behind its K1 kernel on that kernel's stream, the window classes after the sentinel reruns, and
+    // emits the run-length tuples during the walk -- no K3a launch.
+    const bool fused_k2 = !seg_possible && mode == 0 && (a.C == 67 || a.C == 17);
+    a.k2_sel = K2_ALL;
+    a.k2_fused_rle = fused_k2 ? 1 : 0;
     if (seg_possible) (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
     else a.p.win_mask |= 0x80000000u; // k_plan zeroes the counters (see there)
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
@@ -426,6 +361,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, bs);
         else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, bs);
         else bfa_launch_dp_big_nk8(&a, big_grid, bs);
+        if (fused_k2) bfa_launch_backtrace_sel(&a, K2_BIG, 1, dp_grid, bs, 2);
     }
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
@@ -435,8 +371,17 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     else if (nk <= 5) bfa_launch_dp_redo_nk5(&a, mask, mode, stream);
     else bfa_launch_dp_redo_nk8(&a, mask, mode, stream);
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
-    bfa_launch_backtrace(&a, dp_grid, stream);
-    hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
+    // which of the two walk kernels can find work: narrow (Rw <= 4 / R <= 4, and every non-DP item), wide (Rw 6 / 8, R >= 6,
+    // paths beyond 1024 states) -- from the classes that can occur (`mask`) and, for window reruns, the widest path
+    const bool any_wide = (mask & (0x78u | (0xa0u << 8))) != 0 || Lmax > 256;
+    if (fused_k2) {
+        // window / rerun items, fills, items nobody took: wide only if a window item (or its full-layout rerun) can be
+        const bool rest_wide = (mask & (0xa0u << 8)) != 0 || (wmask != 0 && Lmax > 256);
+        bfa_launch_backtrace_sel(&a, K2_REST, 1, dp_grid, stream, rest_wide ? 3 : 1);
+    } else {
+        bfa_launch_backtrace(&a, dp_grid, stream, any_wide ? 3 : 1);
+        hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
+    }
     return (int)hipGetLastError();
 }
 

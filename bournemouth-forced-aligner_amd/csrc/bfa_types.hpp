@@ -88,7 +88,10 @@ struct AlignArgs {
     uint32_t *bp;           // backpointer pool
     int64_t bp_cap;         // dwords
     int64_t bp_per_utt;     // dwords reserved for the one-DP-per-utterance case
+    int32_t k2_sel;         // K2: which items this launch takes (K2_ALL / K2_FULL + R / K2_BIG / K2_REST)
+    int32_t k2_fused_rle;   // K2: every utterance is one item and the walk also emits its tuples (no K3a launch)
 };
+constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
 
 struct ConfArgs {
     const float *logp;
@@ -205,22 +208,25 @@ struct LaunchFan {
     hipEvent_t *joined; // one per aux stream
     hipEvent_t forked;
     int naux, used;
-    hipStream_t pick()
+    unsigned touched = 0; // aux streams that have been forked from the caller's stream in this call
+    // aux stream k (forked from the caller's stream at its first use)
+    hipStream_t lane(int k)
     {
         if (naux <= 0) return main_stream;
-        if (used == 0) (void)hipEventRecord(forked, main_stream);
-        const int k = used % naux;
-        if (used < naux) (void)hipStreamWaitEvent(aux[k], forked, 0);
-        ++used;
+        k %= naux;
+        if (touched == 0) (void)hipEventRecord(forked, main_stream);
+        if (!(touched & (1u << k))) { (void)hipStreamWaitEvent(aux[k], forked, 0); touched |= 1u << k; }
         return aux[k];
     }
+    hipStream_t pick() { return lane(used++); }
     void join()
     {
-        const int n = used < naux ? used : naux;
-        for (int k = 0; k < n; ++k) {
+        for (int k = 0; k < naux; ++k) {
+            if (!(touched & (1u << k))) continue;
             (void)hipEventRecord(joined[k], aux[k]);
             (void)hipStreamWaitEvent(main_stream, joined[k], 0);
         }
+        touched = 0;
         used = 0;
     }
 };
