@@ -88,7 +88,7 @@ Layout layout_for(int B, int Tmax, int Smax, const bfa_params *p)
     return l;
 }
 
-size_t carve_all(Carve &c, int B, int Tmax, int Smax, const bfa_params *p, const Layout &l, bfa::AlignArgs *a,
+size_t carve_all(Carve &c, int B, int Tmax, int Smax, int C, const bfa_params *p, const Layout &l, bfa::AlignArgs *a,
                  bool need_frames)
 {
     const bool seg = segmented_possible(p);
@@ -103,6 +103,10 @@ size_t carve_all(Carve &c, int B, int Tmax, int Smax, const bfa_params *p, const
     auto anchor = c.take<uint8_t>(seg ? (size_t)B * anchor_per_utt : 1);
     auto psil = c.take<float>(seg ? (size_t)B * Tmax : 1);
     auto cand = c.take<int32_t>((size_t)B);
+    // K0's statistics of the boosted rows (reused by K1): only on the 16-rows-per-pass widths with the default flags
+    const bool reuse = seg && (C == 67 || C == 17) && p->boost_targets && p->enforce_minimum && !p->simple;
+    auto row_stats2 = c.take<float>(reuse ? (size_t)B * Tmax * 2 : 1);
+    auto ucand = c.take<uint8_t>((size_t)B);
     auto seg_scratch = c.take<int32_t>(seg ? (size_t)B * scratch_per_utt : 1);
     int32_t *fph = nullptr, *fidx = nullptr;
     if (need_frames) {
@@ -113,6 +117,7 @@ size_t carve_all(Carve &c, int B, int Tmax, int Smax, const bfa_params *p, const
     if (a) {
         a->items = items; a->item_cap = l.item_cap; a->counters = counters; a->umask = umask; a->uT = uT; a->uS = uS;
         a->umode = umode; a->anchor = anchor; a->anchor_per_utt = anchor_per_utt; a->psil = psil; a->cand = cand;
+        a->row_stats2 = reuse ? row_stats2 : nullptr; a->ucand = ucand;
         a->seg_scratch = seg_scratch; a->seg_scratch_per_utt = scratch_per_utt; a->bp = bp; a->bp_cap = (int64_t)B * l.bp_per_utt;
         a->bp_per_utt = l.bp_per_utt;
         if (need_frames) { a->frame_ph = fph; a->frame_idx = fidx; }
@@ -235,10 +240,9 @@ const char *bfa_last_error(bfa_handle h) { return h ? h->err.c_str() : "null han
 size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p)
 {
     if (B <= 0 || Tmax <= 0 || Smax <= 0 || !p) return 0;
-    (void)C;
     const Layout l = layout_for(B, Tmax, Smax, p);
     Carve c(nullptr);
-    return carve_all(c, B, Tmax, Smax, p, l, nullptr, true) + 256;
+    return carve_all(c, B, Tmax, Smax, C, p, l, nullptr, true) + 256;
 }
 
 } // extern "C"
@@ -271,7 +275,7 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
     Carve c((void *)aligned);
     a.frame_ph = out_frame_phoneme;
     a.frame_idx = out_frame_idx;
-    const size_t need = carve_all(c, B, Tmax, Smax, params, l, &a, need_frames) + (aligned - basep);
+    const size_t need = carve_all(c, B, Tmax, Smax, C, params, l, &a, need_frames) + (aligned - basep);
     if (need > workspace_bytes) return fail(h, BFA_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
 
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT;
@@ -367,7 +371,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
     const uintptr_t basep = (uintptr_t)workspace;
     const uintptr_t aligned = (basep + 255) & ~(uintptr_t)255;
     Carve c((void *)aligned);
-    const size_t need = carve_all(c, B, Tmax, Smax, params, l, &a, true) + (aligned - basep);
+    const size_t need = carve_all(c, B, Tmax, Smax, C, params, l, &a, true) + (aligned - basep);
     if (need > workspace_bytes) return fail(h, BFA_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
     a.logp = logp; a.strideB = strideB; a.strideT = strideT;
     a.B = B; a.Tmax = Tmax; a.C = C; a.Smax = Smax;

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
             if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
         }
         (void)fallback_short;
+        if (a.ucand) a.ucand[b] = (seg_candidate && status == BFA_ITEM_OK) ? 1 : 0;
         if (seg_candidate && status == BFA_ITEM_OK) { // k_plan_segmented decides (it may keep this fallback)
             mode = -1 - mode;
             a.cand[atomicAdd(&a.counters[1], 1)] = b;

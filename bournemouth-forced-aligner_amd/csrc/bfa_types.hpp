@@ -65,6 +65,11 @@ struct AlignArgs {
     // that the later sparse readers (confidences, soft boundaries) reconstitute log_prob = (x - max) - logsum with the
     // very same two float32 subtractions (no separate log-softmax pass over the logits)
     float *row_stats;
+    // Silence-anchored mode on the 16-rows-per-pass kernels: the P(SIL) pass (K0) leaves the (maximum, log-sum) of the
+    // BOOSTED rows of every candidate utterance here ([B, Tmax] pairs; nullptr = not in use) and K1's row preparation
+    // reuses them instead of evaluating the softmax of the same rows a second time.  ucand[b] = 1 marks the candidates.
+    float *row_stats2;
+    uint8_t *ucand;
     int32_t B, Tmax, C, Smax;
     const int32_t *T_len, *tokens, *S_len;
     DevParams p;
