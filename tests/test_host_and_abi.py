@@ -200,8 +200,9 @@ def test_textgrid_writer_matches_the_reference_examples():
 
 
 def test_backtrace_kernel_keeps_four_waves_per_simd():
-    """A 4096-utterance batch is only resident at once in K2 if the kernel fits 4 waves per SIMD (<= 128 VGPRs); every
-    new per-layout instantiation of the walk counts against that (the compiler's resource remark is the check)."""
+    """A 4096-utterance batch is only resident at once in K2 if the NARROW walk kernel (window Rw <= 4, full layout
+    R <= 4) fits 4 waves per SIMD (<= 128 VGPRs); every new per-layout instantiation of the walk counts against that
+    (the compiler's resource remark is the check).  The wide kernel (R >= 6, Rw 6 / 8) trades occupancy for registers."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -212,10 +213,14 @@ def test_backtrace_kernel_keeps_four_waves_per_simd():
                           os.path.join(csrc, "bfa_backtrace.hip"), "-o", os.devnull],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    occ = [int(m) for m in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", out.stderr)]
-    assert occ and min(occ) >= 4, out.stderr[-1500:]
-    scratch = [int(m) for m in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-    assert scratch and max(scratch) <= 64, out.stderr[-1500:]  # (a few dwords spill outside the step loops)
+    res = {m.group(1): (int(m.group(2)), int(m.group(3)))
+           for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
+                                out.stderr, re.S)}
+    narrow = [v for k, v in res.items() if "k_backtraceE" in k]
+    wide = [v for k, v in res.items() if "k_backtrace_wide" in k]
+    assert narrow and wide, sorted(res)
+    assert narrow[0][1] >= 4 and narrow[0][0] <= 64, res   # (a few dwords spill outside the step loops)
+    assert wide[0][1] >= 2 and wide[0][0] <= 32, res       # long utterances, few of them: may use more registers
 
 
 # ---- host-side result shaping against the reference's outputs (tests/golden/host_cases.json) ----
