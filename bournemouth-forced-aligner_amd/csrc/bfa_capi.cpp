@@ -126,6 +126,17 @@ size_t carve_all(Carve &c, int B, int Tmax, int Smax, int C, const bfa_params *p
     return align_up(c.off, 256);
 }
 
+// the handle's device is made current for the duration of a call (the caller may have another one current)
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(bfa_handle h)
+    {
+        int cur = -1;
+        if (h && hipGetDevice(&cur) == hipSuccess && cur != h->device) { prev = cur; (void)hipSetDevice(h->device); }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int fail(bfa_handle h, int code, const char *msg)
 {
     if (h) h->err = msg;
@@ -254,6 +265,7 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
                     int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!logp || !tokens || !S_len || !params || !out_segs || !out_seg_count || !out_status || !workspace)
         return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || Smax <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
@@ -331,6 +343,7 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
                     const int32_t *S_len, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!heads || n_heads <= 0 || n_heads > 8) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad head list");
     for (int k = 0; k < n_heads; ++k)
         if (!heads[k].logits || !heads[k].out_row_stats) return fail(h, BFA_ERR_INVALID_ARGUMENT, "head without logits / out_row_stats");
@@ -362,6 +375,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
                           void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!logp || !tokens || !S_len || !params || !out || !workspace) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || Smax <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
     if (C != 67 && C != 17) return fail(h, BFA_ERR_UNSUPPORTED, "bfa_prepare_emissions supports C = 67 and C = 17");
@@ -392,6 +406,7 @@ int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t s
                     float *out_conf, int32_t *out_item_status, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!logp || !segs || !seg_count || !out_conf) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
     bfa::ConfArgs a;
@@ -407,9 +422,10 @@ int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t s
                     int boundary_softness, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!logp || !S_len || !segs || !seg_count) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
-    if (seg_cap > 4096) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 4096 in bfa_postprocess");
+    if (seg_cap > 6500) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 6500 in bfa_postprocess (24 bytes of LDS per tuple)");
     // core.py:699-701 : python `10.0 ** -n` is libm pow on doubles
     const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)boundary_softness);
     const int rc = bfa_launch_postprocess(logp, row_stats, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, extend,
@@ -422,6 +438,7 @@ int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out
                     int C, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!logits || !out || rows < 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");
     if (C < 16 || C > bfa::MAX_C) return fail(h, BFA_ERR_UNSUPPORTED, "C must be in [16,128]");
     if (rows == 0) return BFA_OK;
@@ -434,6 +451,7 @@ int bfa_stitch_windows(bfa_handle h, const float *window_logits, int B, int NW, 
                        int total_frames, float *out, int64_t out_strideB, int64_t out_strideT, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
     if (!window_logits || !weights || !out || B < 0 || NW < 0 || F <= 0 || C <= 0 || total_frames < 0 ||
         out_strideT < C)
         return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");

@@ -160,6 +160,10 @@ extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.S_len = S_len;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.extend = extend; a.th1 = th1; a.th2 = th2;
     const size_t lds = (size_t)seg_cap * (8 + sizeof(bfa_segment));
+    if (lds > 48 * 1024) { // beyond the default dynamic-LDS limit (seg_cap = Tmax + 1 with ignore_noise = False)
+        (void)hipFuncSetAttribute((const void *)k_postprocess<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_postprocess<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (row_stats) hipLaunchKernelGGL(k_postprocess<true>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL(k_postprocess<false>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();

@@ -204,6 +204,10 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
             na = silences(ps, T, (float)nt, mf, aud, aud_cap);
         }
         if (na == 0 && S > 200 && mf > 3) { mf = 3; na = silences(ps, T, 0.9f, mf, aud, aud_cap); }
+        // More silence runs than the scratch holds (runs only need one silent window followed by a non-silent one, so
+        // there can be about nwin / 2 of them -- P(SIL) oscillating around the threshold at every frame): reported as
+        // BFA_ITEM_TOO_LARGE, never as a silently different (standard-mode) alignment.
+        if (na < 0) { if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; } return; }
         if (na <= 0) ok = false; // :315-320
     }
     // ---- _match_silences :226-266
@@ -317,6 +321,8 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
             // sub-silences of the padded slice get +5 on blank and a re-normalisation, once per
             // (possibly overlapping) detected segment (:415-419, :543-561)
             const int nsub = silences(ps + psx, Ts, 0.8f, mf, sub, aud_cap);
+            // scratch or anchor pool exhausted (pathological inputs, see above): flag the utterance instead of skipping
+            if ((nsub < 0 || (nsub > 0 && anch_used + Ts > a.anchor_per_utt)) && writer) a.status[b] = BFA_ITEM_TOO_LARGE;
             if (nsub > 0 && anch_used + Ts <= a.anchor_per_utt) {
                 uint8_t *ac = apool + anch_used;
                 if (COOP) { // one frame per lane: how many detected segments cover it
@@ -372,8 +378,9 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a)
         const int b = a.cand[ci];
         const int T = a.uT[b], S = a.uS[b];
         const float *ps = a.psil + (int64_t)b * a.Tmax;
-        // a silence run is at least min_k frames long (anchors, or 3 on the S > 200 retry): T / min_k + 1 runs at most;
-        // SIL groups alternate with other tokens: (S + 1) / 2 at most
+        // budget of the cooperative path: T / min_k + 1 silence runs (min_k = anchors, or 3 on the S > 200 retry) -- real
+        // posteriors stay far below it; the true worst case is ~nwin / 2 overlapping runs, which overflows the scratch and
+        // is reported per utterance (see plan_candidate).  SIL groups alternate with other tokens: (S + 1) / 2 at most
         const int min_k = (S > 200 && a.p.anchors > 3) ? 3 : (a.p.anchors > 0 ? a.p.anchors : 1);
         const bool coop = T <= PLAN_LDS_FRAMES && (T / min_k + 2 <= PLAN_LDS_SILS) && ((S + 1) / 2 + 1 <= PLAN_LDS_GROUPS);
         __builtin_amdgcn_wave_barrier(); // the previous candidate's readers are done
