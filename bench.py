@@ -661,7 +661,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: ONE unsorted mixed-length call T~U{200..3000}, S=T//25")
     ap.add_argument("--global-batch", type=int, default=32768, help="c4: utterances over all ranks")
-    ap.add_argument("--chunk", type=int, default=4096, help="c4: utterances per bfa_align_batch call")
+    ap.add_argument("--chunk", type=int, default=16384, help="c4: utterances per bfa_align_batch call (one call per rank when the shard is smaller)")
     ap.add_argument("--seed", type=int, default=1004, help="c4: generator seed")
     ap.add_argument("--parity-sample", type=int, default=256, help="c4: utterances rank 0 checks against the oracle")
     ap.add_argument("--dry-run", action="store_true", help="launch + partition + gather plumbing on gloo, no GPU work")
