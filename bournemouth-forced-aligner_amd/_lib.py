@@ -93,16 +93,19 @@ def lib():
 _handles = {}
 
 
-def handle(device_index):
-    """One bfa handle per GPU per process."""
-    if device_index not in _handles:
+def handle(device_index, slot=0):
+    """One bfa handle per GPU per process -- plus one per extra `slot` for callers that keep several calls in flight on
+    different streams (a handle owns the auxiliary streams its class kernels fan out to; calls that share a handle
+    queue behind each other there)."""
+    key = (device_index, slot)
+    if key not in _handles:
         h = ctypes.c_void_p()
         rc = lib().bfa_create(ctypes.byref(h), int(device_index))
         if rc != BFA_OK:
             raise RuntimeError(f"bfa_create(device={device_index}) failed with status {rc} "
                                f"(no GPU visible? this package has no CPU path)")
-        _handles[device_index] = h
-    return _handles[device_index]
+        _handles[key] = h
+    return _handles[key]
 
 
 def check(rc, h, what):

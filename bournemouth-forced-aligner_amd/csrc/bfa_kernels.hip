@@ -340,8 +340,11 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // class right behind its K1 kernel on that kernel's stream, the window classes after the sentinel reruns, and
     // emits the run-length tuples during the walk -- no K3a launch.
     const bool fused_k2 = !seg_possible && mode == 0 && (a.C == 67 || a.C == 17);
+    const bool per_class_k2 = fused_k2; // (measured for the silence-anchored mode as well: every extra K2 launch re-scans
+                                        // the long item list of that mode, 1.11 -> 1.18 ms; it keeps the single walk after the join)
     a.k2_sel = K2_ALL;
     a.k2_fused_rle = fused_k2 ? 1 : 0;
+    a.k2_per_class = per_class_k2 ? 1 : 0;
     if (seg_possible) (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
     else a.p.win_mask |= 0x80000000u; // k_plan zeroes the counters (see there)
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
@@ -362,7 +365,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, bs);
         else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, bs);
         else bfa_launch_dp_big_nk8(&a, big_grid, bs);
-        if (fused_k2) bfa_launch_backtrace_sel(&a, K2_BIG, 1, dp_grid, bs, 2);
+        if (per_class_k2) bfa_launch_backtrace_sel(&a, K2_BIG, fused_k2 ? 1 : 0, dp_grid, bs, 2);
     }
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
@@ -375,10 +378,11 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // which of the two walk kernels can find work: narrow (Rw <= 4 / R <= 4, and every non-DP item), wide (Rw 6 / 8, R >= 6,
     // paths beyond 1024 states) -- from the classes that can occur (`mask`) and, for window reruns, the widest path
     const bool any_wide = (mask & (0x78u | (0xa0u << 8))) != 0 || Lmax > 256;
-    if (fused_k2) {
+    if (per_class_k2) {
         // window / rerun items, fills, items nobody took: wide only if a window item (or its full-layout rerun) can be
         const bool rest_wide = (mask & (0xa0u << 8)) != 0 || (wmask != 0 && Lmax > 256);
-        bfa_launch_backtrace_sel(&a, K2_REST, 1, dp_grid, stream, rest_wide ? 3 : 1);
+        bfa_launch_backtrace_sel(&a, K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
+        if (!fused_k2) hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     } else {
         bfa_launch_backtrace(&a, dp_grid, stream, any_wide ? 3 : 1);
         hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);

@@ -124,6 +124,7 @@ class ViterbiDecoder:
         # posteriors that are known to keep path scores above the -1000 sentinel (bfa_params.window_max_tokens)
         self.window_max_tokens = None
         self.window_max_frames = None   # likewise for the frame limit (bfa_params.window_max_frames)
+        self.handle_slot = 0            # which of the process's handles this decoder uses (see _lib.handle)
 
     def set_blank_id(self, blank_id):
         """forced_alignment.py:25-27"""
@@ -292,7 +293,7 @@ class ViterbiDecoder:
                                anchor_pauses, simple, seg_cap, max_blanks, class_mask)
         dev, lp, T_len = c["dev"], c["lp"], c["T_len"]
         L = _lib.lib()
-        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(), self.handle_slot)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             rc = L.bfa_align_batch(h, lp.data_ptr(), lp.stride(0), lp.stride(1), c["B"], c["Tmax"], c["C"],
