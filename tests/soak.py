@@ -24,6 +24,7 @@ def main():
     dev = torch.device("cuda", 0)
     bad = 0
     bad2 = 0
+    bad3 = 0
     items = 0
     t0 = time.time()
     for it in range(nb):
@@ -122,9 +123,52 @@ def main():
                     bad2 += 1
                     print(f"POST-DP MISMATCH batch {it} item {b}: C={C} T={int(T_len[b])} S={int(S_len[b])} conf_ok={okc} post_ok={okp} "
                           f"softness={soft}", flush=True)
+        # ---- fused front end (bfa_align_heads): the same batch as RAW logits (scaled / shifted log-probs) against the
+        # two-pass path (bfa_log_softmax, then bfa_align_batch) -- states, tuples, status, then confidences and the
+        # soft-boundary stage from (logits, row statistics); every array bitwise
+        if C >= 16 and not simple and n > 0 and it % 2 == 0:
+            from bournemouth_forced_aligner_amd import calculate_confidences_batch, log_softmax
+            from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+            from bournemouth_forced_aligner_amd.utils import postprocess_batch
+            logits = torch.from_numpy(lp).to(dev) * float(rng.choice([1.0, 1.7, 0.6])) + float(rng.normal(0, 2))
+            lp2 = log_softmax(logits)
+            two = au.viterbi_decoder.align_batch(lp2, torch.from_numpy(tk), T_len, S_len, boost_targets=boost,
+                                                 enforce_minimum=enf, anchor_pauses=anchors > 0, seg_cap=lp.shape[1] + 1)
+            (fus, stats), = align_heads([au], [logits], [torch.from_numpy(tk)], T_len, S_len, boost_targets=boost,
+                                        enforce_minimum=enf, seg_cap=lp.shape[1] + 1)
+            torch.cuda.synchronize()
+            same = torch.equal(two.status, fus.status) and torch.equal(two.seg_count, fus.seg_count)
+            if same and bool((two.status == 0).all()):
+                mk = torch.arange(two.segs.shape[1], device=dev)[None, :] < two.seg_count[:, None]
+                same = torch.equal(two.segs[mk], fus.segs[mk]) and \
+                    torch.equal(two.frame_phonemes, fus.frame_phonemes) and torch.equal(two.frame_phonemes_idx, fus.frame_phonemes_idx)
+                if same:
+                    c1, _ = calculate_confidences_batch(lp2, two.segs, two.seg_count)
+                    c2, _ = calculate_confidences_batch(logits, fus.segs, fus.seg_count, row_stats=stats)
+                    s1, n1 = two.segs.clone(), two.seg_count.clone()
+                    s2, n2 = fus.segs.clone(), fus.seg_count.clone()
+                    Sd = torch.from_numpy(np.asarray(S_len, np.int32))
+                    postprocess_batch(lp2, Sd, s1, n1, extend=True, boundary_softness=3)
+                    postprocess_batch(logits, Sd, s2, n2, extend=True, boundary_softness=3, row_stats=stats)
+                    torch.cuda.synchronize()
+                    m = torch.arange(c1.shape[1], device=dev)[None, :] < two.seg_count[:, None]
+                    same = torch.equal(c1.view(torch.int32)[m], c2.view(torch.int32)[m]) and torch.equal(n1, n2)
+                    if same:
+                        m2 = torch.arange(s1.shape[1], device=dev)[None, :] < n1[:, None]
+                        same = torch.equal(s1[m2], s2[m2])
+            if not same:
+                bad3 += 1
+                why = []
+                if not torch.equal(two.status, fus.status): why.append(f"status {two.status.tolist()} vs {fus.status.tolist()}")
+                elif not torch.equal(two.seg_count, fus.seg_count): why.append("seg_count")
+                elif not torch.equal(two.frame_phonemes, fus.frame_phonemes): 
+                    d = (two.frame_phonemes != fus.frame_phonemes).nonzero()
+                    why.append(f"frames differ at {d[:4].tolist()} T_len={[int(T_len[int(i)]) for i in d[:4, 0]]} Tmax={lp.shape[1]}")
+                else: why.append("segs/conf/post")
+                print(f"FUSED-vs-TWO-PASS MISMATCH batch {it}: C={C} anchors={anchors} tf={tf} ign={ign} boost={boost} enf={enf} regime={regime} {why}", flush=True)
     print(f"soak: {items} utterances in {nb} batches, {bad} mismatching, {bad2} post-DP mismatches, "
-          f"{time.time() - t0:.0f} s (seed {seed})")
-    return 1 if (bad or bad2) else 0
+          f"{bad3} fused-front-end mismatches, {time.time() - t0:.0f} s (seed {seed})")
+    return 1 if (bad or bad2 or bad3) else 0
 
 
 if __name__ == "__main__":
