@@ -683,12 +683,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1004, help="c4: generator seed")
     ap.add_argument("--parity-sample", type=int, default=256, help="c4: utterances rank 0 checks against the oracle")
     ap.add_argument("--dry-run", action="store_true", help="launch + partition + gather plumbing on gloo, no GPU work")
+    ap.add_argument("--force-group", action="store_true",
+                    help="initialise the process group even at world size 1 (exercises the N > 1 code path of the headline mode)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
 
-    rk = Ranks(args, need_group=(args.config == "c4"))
+    rk = Ranks(args, need_group=(args.config == "c4" or args.force_group))
     if args.ragged:
         ragged_main(args, rk)
     elif args.config == "c4":

@@ -72,3 +72,12 @@ def test_config_c3_slice_against_oracle(ora, gpu_device):
     """BASELINE.json configs[2] (the headline batch=4096, T=1000, |tokens|=40) aligned at full batch size, a
     512-utterance slice of it compared with the oracle (framewise states, tuples, confidence bit patterns)."""
     _batch_vs_oracle(ora, gpu_device, 4096, 1000, 40, 1003, 512)
+
+
+def test_headline_mode_multi_rank_path_on_nccl(gpu_device):
+    """The N > 1 leg of the headline mode (barriers, max over ranks, sharding.gather_results over RCCL, per-rank device
+    list) with a one-rank `nccl` group: what the driver's `torch.distributed.run ... bench.py --gpus N` executes."""
+    out = _bench_json(["--force-group", "--steps", "5", "--warmup", "2", "--no-cpu", "--settle-ms", "10"])
+    assert out["n_gpus"] == 1 and out["gather_ms"] is not None and len(out["rank_ms_per_step"]) == 1
+    assert out["ranks"][0]["device"] == "cuda:0" and out["value"] > 1e9 and out["roofline"]["frac"] > 0.2
+    assert out["settle"]["first_window"]["ms_per_step"] > 0
