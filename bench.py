@@ -613,7 +613,7 @@ def ragged_main(args, rk):
     from bournemouth_forced_aligner_amd import AlignmentUtils
     dev, rank = rk.dev, rk.rank
     C, B = args.classes, args.batch
-    lp, tk, T_len, S_len = synth_ragged(B, 200, 3000, C, 1004 + rank, dev)
+    lp, tk, T_len, S_len = synth_ragged(B, args.tlo, args.thi, C, 1004 + rank, dev)
     au = AlignmentUtils(blank_id=C - 1, silence_id=0)
     au.viterbi_decoder.window_max_frames = args.win_frames or None
     au.viterbi_decoder.window_max_tokens = args.win_tokens or None
@@ -632,7 +632,7 @@ def ragged_main(args, rk):
     S_np, T_np = S_len.numpy().astype(np.int64), T_len.numpy().astype(np.int64)
     nbytes = int(((4 * C + (4 * S_np + 1 + 3) // 4 + 8) * T_np).sum())
     if rank == 0:
-        print(json.dumps({"workload": f"ragged batch={B} T~U[200,3000] S=T//25 C={C}", "frames": frames,
+        print(json.dumps({"workload": f"ragged batch={B} T~U[{args.tlo},{args.thi}] S=T//25 C={C}", "frames": frames,
                           "ms_per_step": el * 1e3, "frames_per_s": frames / el,
                           "algorithmic_bytes": nbytes, "hbm_frac": nbytes / el / 1e9 / HBM_PEAK_GBS,
                           "status_ok": bool((res.status.cpu() == 0).all())}))
@@ -662,6 +662,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["headline", "c4"], default="headline")
+    ap.add_argument("--tlo", type=int, default=200, help="--ragged: shortest utterance")
+    ap.add_argument("--thi", type=int, default=3000, help="--ragged: longest utterance")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--tokens", type=int, default=40)

@@ -90,7 +90,7 @@ __device__ int detect_silence(const float *ps, int Tx, float thr, int k, int32_t
     return n;
 }
 
-// The same on a P(SIL) vector staged in LDS, by the whole wavefront (all lanes follow the same control flow).  The
+// The same by the whole wavefront (all lanes follow the same control flow; `ps` in global memory or LDS).  The
 // running float64 sum of torch.cumsum stays serial (its additions are not reorderable), but it is walked once per
 // call -- cs[i] = float32(cumsum[i]) goes to LDS -- and the window averages, the threshold test and the run
 // bookkeeping work on 64 windows at a time (ballot + bit scans).
@@ -104,13 +104,28 @@ __device__ int detect_silence_w(const float *ps, int Tx, float thr, int k, int32
         // so that no memory latency sits in the serial chain.  Lane l adds the values j <= l of the slice (in order;
         // adding 0.0 for the others changes nothing), so it ends with cumsum[base + l]; lane 63's sum carries over.
         double carry = 0.0;
+        float xn = (lane < Tx) ? ps[lane] : 0.0f; // (values past Tx add 0.0)
         for (int base = 0; base < Tx; base += 64) {
-            const float x = (base + lane < Tx) ? ps[base + lane] : 0.0f; // (values past Tx add 0.0)
+            const float x = xn;
+            xn = (base + 64 + lane < Tx) ? ps[base + 64 + lane] : 0.0f; // the next slice is in flight during this one's chain
             double acc = carry;
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
-                acc += (double)((lane >= j) ? xj : 0.0f);
+            // Step j: the lanes >= j add x[j].  The lane set shrinks by one lane per step, so it is kept in EXEC itself and
+            // shifted by the scalar unit; a step is three vector instructions (two broadcasts, one add).  Written out by
+            // the compiler from `acc += (lane >= j) ? x[j] : 0` it was eight: the 64 lane masks did not fit the scalar
+            // registers and came back through v_readlane, two per step, followed by two selects.
+            {
+                const long long xb = __builtin_bit_cast(long long, (double)x); // converted once per lane, not once per step
+                const int xlo = (int)(xb & 0xffffffffll), xhi = (int)(xb >> 32);
+#define BFA_CS_FIRST(J) "v_readlane_b32 s20, %[xlo], " #J "\n\tv_readlane_b32 s21, %[xhi], " #J "\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+#define BFA_CS_STEP(J) "v_readlane_b32 s20, %[xlo], " #J "\n\tv_readlane_b32 s21, %[xhi], " #J "\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                asm volatile(
+                    BFA_CS_FIRST(0) BFA_CS_STEP(1) BFA_CS_STEP(2) BFA_CS_STEP(3) BFA_CS_STEP(4) BFA_CS_STEP(5) BFA_CS_STEP(6) BFA_CS_STEP(7) BFA_CS_STEP(8) BFA_CS_STEP(9) BFA_CS_STEP(10) BFA_CS_STEP(11) BFA_CS_STEP(12) BFA_CS_STEP(13) BFA_CS_STEP(14) BFA_CS_STEP(15) BFA_CS_STEP(16) BFA_CS_STEP(17) BFA_CS_STEP(18) BFA_CS_STEP(19) BFA_CS_STEP(20) BFA_CS_STEP(21) BFA_CS_STEP(22) BFA_CS_STEP(23) BFA_CS_STEP(24) BFA_CS_STEP(25) BFA_CS_STEP(26) BFA_CS_STEP(27) BFA_CS_STEP(28) BFA_CS_STEP(29) BFA_CS_STEP(30) BFA_CS_STEP(31) BFA_CS_STEP(32) BFA_CS_STEP(33) BFA_CS_STEP(34) BFA_CS_STEP(35) BFA_CS_STEP(36) BFA_CS_STEP(37) BFA_CS_STEP(38) BFA_CS_STEP(39) BFA_CS_STEP(40) BFA_CS_STEP(41) BFA_CS_STEP(42) BFA_CS_STEP(43) BFA_CS_STEP(44) BFA_CS_STEP(45) BFA_CS_STEP(46) BFA_CS_STEP(47) BFA_CS_STEP(48) BFA_CS_STEP(49) BFA_CS_STEP(50) BFA_CS_STEP(51) BFA_CS_STEP(52) BFA_CS_STEP(53) BFA_CS_STEP(54) BFA_CS_STEP(55) BFA_CS_STEP(56) BFA_CS_STEP(57) BFA_CS_STEP(58) BFA_CS_STEP(59) BFA_CS_STEP(60) BFA_CS_STEP(61) BFA_CS_STEP(62) BFA_CS_STEP(63)
+                    "s_mov_b64 exec, -1"
+                    : [acc] "+v"(acc)
+                    : [xlo] "v"(xlo), [xhi] "v"(xhi)
+                    : "scc", "s20", "s21");
+#undef BFA_CS_FIRST
+#undef BFA_CS_STEP
             }
             if (base + lane < Tx) cs[base + lane] = (float)acc;
             const long long bits = __builtin_bit_cast(long long, acc);
@@ -190,9 +205,29 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
     bool ok = true;
     // ---- _find_target_sil_groups :203-224
     int ng = 0;
-    for (int i = 0; i < S;) {
-        if (tok[i] == p.sil) { const int st = i; while (i < S && tok[i] == p.sil) ++i; groups[2 * ng] = st; groups[2 * ng + 1] = i; ++ng; }
-        else ++i;
+    if (COOP) { // 64 targets per load (a serial walk over global memory pays one memory round trip per target)
+        bool in_g = false;
+        int st = 0;
+        for (int base = 0; base < S; base += 64) {
+            const int nv = min(64, S - base);
+            const unsigned long long vmask = (nv == 64) ? ~0ull : ((1ull << nv) - 1ull);
+            const unsigned long long bits = __ballot(base + lane < S && tok[min(base + lane, S - 1)] == p.sil) & vmask;
+            int pos = 0;
+            while (pos < nv) {
+                const unsigned long long rest = (in_g ? (~bits & vmask) : bits) >> pos; // next change of state
+                if (rest == 0ull) break;
+                const int j = pos + __builtin_ctzll(rest);
+                if (!in_g) { in_g = true; st = base + j; }
+                else { in_g = false; groups[2 * ng] = st; groups[2 * ng + 1] = base + j; ++ng; }
+                pos = j + 1;
+            }
+        }
+        if (in_g) { groups[2 * ng] = st; groups[2 * ng + 1] = S; ++ng; }
+    } else {
+        for (int i = 0; i < S;) {
+            if (tok[i] == p.sil) { const int st = i; while (i < S && tok[i] == p.sil) ++i; groups[2 * ng] = st; groups[2 * ng + 1] = i; ++ng; }
+            else ++i;
+        }
     }
     if (ng == 0) ok = false; // :293-295
     int mf = p.anchors, na = 0;
@@ -213,13 +248,23 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
     // ---- _match_silences :226-266
     int nm = 0;
     if (ok) {
+        // COOP: the relative position of every audio silence once, one per lane (two float64 divisions each; the serial
+        // loop below would evaluate them for every (group, silence) pair it visits) -- parked in the sub-silence scratch,
+        // which is not in use before the pieces are emitted
+        double *apos = reinterpret_cast<double *>(sub);
+        if (COOP) {
+            for (int ai = lane; ai < na; ai += 64) apos[ai] = (double)(aud[2 * ai] + aud[2 * ai + 1]) / 2.0 / (double)T;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         int audio_idx = 0;
         for (int gi = 0; gi < ng; ++gi) {
             const double tp = (double)(groups[2 * gi] + groups[2 * gi + 1]) / 2.0 / (double)S;
             int best = -1;
             double bd = __builtin_inf();
             for (int ai = audio_idx; ai < na; ++ai) {
-                const double ap = (double)(aud[2 * ai] + aud[2 * ai + 1]) / 2.0 / (double)T;
+                const double ap = COOP ? apos[ai] : (double)(aud[2 * ai] + aud[2 * ai + 1]) / 2.0 / (double)T;
                 const double d = __builtin_fabs(tp - ap);
                 if (d < bd) { bd = d; best = ai; }
                 else if (d > bd) break;
@@ -359,17 +404,20 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
     }
 }
 
-// one wavefront per candidate: the lanes stage its P(SIL) vector in LDS and lane 0 plans with LDS scratch (the
-// planner walks these arrays several times with serial, dependent accesses -- from global memory that latency was the
-// whole kernel time).  Utterances whose worst-case counts exceed the LDS arrays use the global scratch instead.
+// one wavefront per candidate, planning with LDS scratch (the planner walks its run / group / segment arrays several
+// times with serial, dependent accesses -- from global memory that latency was the whole kernel time).  Utterances whose
+// worst-case counts exceed the LDS arrays use the global scratch instead.
 constexpr int PLAN_LDS_FRAMES = 2048;
 constexpr int PLAN_LDS_SILS = 128;  // audio silences / sub-silences (pairs)
 constexpr int PLAN_LDS_GROUPS = 64; // target SIL groups / matches (pairs)
 
-__global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a)
+// `lds_frames` (a multiple of 64, <= PLAN_LDS_FRAMES): frames of the staged cumulative sums -- sized by the batch's Tmax,
+// so that a batch of short utterances keeps more planners resident per CU (they are latency chains, LDS is their limit)
+__global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames)
 {
-    __shared__ float sps[PLAN_LDS_FRAMES], scs[PLAN_LDS_FRAMES];
-    __shared__ int32_t s_aud[2 * PLAN_LDS_SILS], s_sub[2 * PLAN_LDS_SILS];
+    extern __shared__ __attribute__((aligned(16))) float plan_dyn[];
+    float *scs = plan_dyn; // float32(cumsum) of the vector under the sliding window (detect_silence_w)
+    __shared__ __attribute__((aligned(8))) int32_t s_aud[2 * PLAN_LDS_SILS], s_sub[2 * PLAN_LDS_SILS]; // (s_sub doubles as PLAN_LDS_SILS float64)
     __shared__ int32_t s_groups[2 * PLAN_LDS_GROUPS], s_match[2 * PLAN_LDS_GROUPS];
     __shared__ SegRec s_segs[2 * PLAN_LDS_GROUPS + 4];
     const int lane = threadIdx.x & 63;
@@ -382,17 +430,16 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a)
         // posteriors stay far below it; the true worst case is ~nwin / 2 overlapping runs, which overflows the scratch and
         // is reported per utterance (see plan_candidate).  SIL groups alternate with other tokens: (S + 1) / 2 at most
         const int min_k = (S > 200 && a.p.anchors > 3) ? 3 : (a.p.anchors > 0 ? a.p.anchors : 1);
-        const bool coop = T <= PLAN_LDS_FRAMES && (T / min_k + 2 <= PLAN_LDS_SILS) && ((S + 1) / 2 + 1 <= PLAN_LDS_GROUPS);
+        const bool coop = T <= lds_frames && (T / min_k + 2 <= PLAN_LDS_SILS) && ((S + 1) / 2 + 1 <= PLAN_LDS_GROUPS);
         __builtin_amdgcn_wave_barrier(); // the previous candidate's readers are done
         PlanScratch sc;
         if (coop) { // wave-uniform
-            for (int t = lane; t < T; t += 64) sps[t] = ps[t];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // P(SIL) itself stays in global memory: every pass over it is a 64-wide coalesced read one slice ahead of
+            // the serial sum, and without a second staged vector all 16 planners of a CU's share of a 4096-utterance
+            // batch are resident at once (LDS was the limit: 12 KB each at T = 1000, 2.5 rounds of ~70 us)
             sc.groups = s_groups; sc.aud = s_aud; sc.sub = s_sub; sc.match = s_match; sc.segs = s_segs;
             sc.aud_cap = PLAN_LDS_SILS; sc.cs = scs;
-            plan_candidate<true>(a, b, sps, sc, lane);
+            plan_candidate<true>(a, b, ps, sc, lane);
         } else if (lane == 0) {
             int32_t *scr = a.seg_scratch + (int64_t)b * a.seg_scratch_per_utt;
             sc.groups = scr; scr += 2 * (a.Smax + 2);
@@ -423,5 +470,8 @@ extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t 
     else if (nk <= 2) hipLaunchKernelGGL(k_silprob<2>, dim3(grid), dim3(64), 0, stream, a);
     else if (nk <= 5) hipLaunchKernelGGL(k_silprob<5>, dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(k_silprob<8>, dim3(grid), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(k_plan_seg, dim3(a.B < 16384 ? a.B : 16384), dim3(64), 0, stream, a);
+    // (cutting the batch into slices so that the planner of one slice runs beside the row pass of the next was measured
+    // and lost: the row pass slows down by more than the planner hides, 1.12 -> 1.17-1.23 ms per step)
+    const int lds_frames = a.Tmax >= PLAN_LDS_FRAMES ? PLAN_LDS_FRAMES : ((a.Tmax + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_plan_seg, dim3(a.B < 16384 ? a.B : 16384), dim3(64), lds_frames * sizeof(float), stream, a, lds_frames);
 }

@@ -9,8 +9,9 @@ OUT=../../tools/ubench/dbg/$NAME
 mkdir -p $OUT
 ALL="bfa_kernels.hip bfa_dp_nk2.hip bfa_dp_nk5.hip bfa_dp_nk8.hip bfa_backtrace.hip bfa_segment.hip bfa_post.hip bfa_stitch.hip bfa_capi.cpp"
 SEL=${*:-$ALL}
-for f in $SEL; do /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f -o $OUT/$f.o & done
-wait
+PIDS=""
+for f in $SEL; do rm -f $OUT/$f.o; /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f -o $OUT/$f.o & PIDS="$PIDS $!"; done
+for p in $PIDS; do wait $p || { echo "variant.sh: a compile failed"; exit 1; }; done
 OBJS=""
 for f in $ALL; do if [ -f $OUT/$f.o ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS build/$f.o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ubench/dbg/libbfa_$NAME.so $OBJS
