@@ -11,6 +11,7 @@
 //
 // No MFMA anywhere: this is a memory-streaming scan with ~13 float ops per CTC state per frame.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "bfa_assort.hpp"
 #include "bfa_softmax.hpp"
@@ -384,7 +385,8 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         bfa_launch_backtrace_sel(&a, K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
         if (!fused_k2) hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     } else {
-        bfa_launch_backtrace(&a, dp_grid, stream, any_wide ? 3 : 1);
+        static const int k2_env = [] { const char *e = getenv("BFA_K2_GRID"); return e ? atoi(e) : 0; }(); // (measurement switch)
+        bfa_launch_backtrace(&a, k2_env > 0 ? k2_env : dp_grid, stream, any_wide ? 3 : 1);
         hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     }
     return (int)hipGetLastError();

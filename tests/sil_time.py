@@ -23,7 +23,7 @@ for _ in range(NB):
     lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=9.0, sil_rate=1 / 12, sil_len=(12, 40))
     lps.append(lp); toks.append(tk)
 lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
-rep = 8
+rep = int(os.environ.get("BFA_SIL_REP", "8"))  # batch = 512 * rep
 lpd = torch.from_numpy(lp).to(dev).repeat(rep, 1, 1)
 tkd = torch.from_numpy(tk).repeat(rep, 1)
 Tl = np.tile(T_len, rep); Sl = np.tile(S_len, rep)
