@@ -160,7 +160,19 @@ def headline_main(args, rk):
     dev, rank, world, dist = rk.dev, rk.rank, rk.world, rk.dist
     B, T, S, C = args.batch, args.frames, args.tokens, args.classes
     blank, sil = C - 1, 0
-    nbuf = max(2, args.inflight)
+    # --pipeline n >= 2 (default 2): n decoders (own library handle, workspace, outputs) take turns on ONE stream and share
+    # a tail stream (include/bfa.h, bfa_set_tail_stream): planning + K1 of step i+1 start as soon as K1 of step i has
+    # ended, while the walk / run-length encoding of step i runs beside them.  --inflight n is the older form (whole steps
+    # on n streams: their K1 kernels overlap each other and a launch's duration stops being a measure of the kernel).
+    # Batches in flight (default 3): step i runs on stream i % 3 with decoder i % 3 (own library handle, workspace and
+    # outputs), so the tail of a step (rerun launch, walk, run-length encoding: ~65 us of latency chains that leave the
+    # machine mostly idle) and the ramp-down of its K1 overlap the K1 of the next steps.  `value` stays frames / wall time.
+    # The K1 launches of different steps then overlap each other: a launch's own duration (kernel_ms) is no longer the
+    # time the kernel needs for a batch, so the roofline prices the kernel by the time it was running AT ALL -- the union
+    # of the launch intervals (bfa_profile_collect_spans) -- see `roofline` below.
+    inflight = args.inflight if args.inflight is not None else 3
+    npipe = args.pipeline if (inflight <= 1 and args.pipeline > 1) else 1
+    nbuf = max(2, inflight, npipe)
     # distinct batches so consecutive steps never stream the same 1.1 GB (> the 256 MB Infinity Cache anyway)
     bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
     if os.environ.get("BFA_BENCH_SAME_INPUT"):  # (experiment: every utterance reads utterance 0 -> cache-resident rows)
@@ -168,19 +180,27 @@ def headline_main(args, rk):
     T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
     S_len = torch.full((B,), S, dtype=torch.int32, device=dev)
     # reference defaults: anchors 10, boost, floor, truly_forced.  One decoder (= one workspace) per batch in flight.
-    aus = [AlignmentUtils(blank_id=blank, silence_id=sil) for _ in range(max(1, args.inflight))]
+    aus = [AlignmentUtils(blank_id=blank, silence_id=sil) for _ in range(max(1, inflight, npipe))]
+    for k, x in enumerate(aus):
+        x.viterbi_decoder.handle_slot = k
     au = aus[0]
     lib = _lib.lib()
-    h = _lib.handle(rk.local_rank)
+    hs = [_lib.handle(rk.local_rank, k) for k in range(len(aus))]
+    # (a stream of its own priority gets a hardware queue of its own; streams of one priority share a few queues, and a tail
+    # stream that lands on the queue of the launch stream would run in submission order behind the next K1)
+    tail_prio = int(os.environ.get("BFA_BENCH_TAIL_PRIO", "-1"))
+    tail = torch.cuda.Stream(device=dev, priority=tail_prio) if npipe > 1 else None
 
     # the lengths are known on the host (constant here), and the synthetic targets never contain SIL:
     # tell the library which K1 register class occurs so that it does not launch the empty ones
     hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False, n_classes=(None if args.no_window else C))
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)] if inflight > 1 else None
 
     def step(i):
         lp, tk = bufs[i % nbuf]
+        if tail is not None:
+            return aus[i % npipe].decode_alignments_device(lp, tk, T_len, S_len, class_mask=hint, tail_stream=tail)
         if streams is None:
             return au.decode_alignments_device(lp, tk, T_len, S_len, class_mask=hint)
         # batches i and i+1 on different streams with their own workspaces: the latency-bound tail of one
@@ -202,9 +222,12 @@ def headline_main(args, rk):
 
     def timed_window():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; K1 events collected."""
-        lib.bfa_profile_enable(h, k1_every)
+        for h in hs:
+            lib.bfa_profile_enable(h, k1_every)
         rk.barrier()
         torch.cuda.synchronize()
+        base = torch.cuda.Event(enable_timing=True)
+        base.record()
         t0 = time.perf_counter()
         r = None
         for i in range(args.steps):
@@ -213,10 +236,15 @@ def headline_main(args, rk):
         mine = time.perf_counter() - t0
         rk.barrier()
         el = time.perf_counter() - t0
-        lib.bfa_profile_enable(h, 0)
-        k1 = (ctypes.c_float * max(1, args.steps))()
-        n = lib.bfa_profile_collect(h, k1, args.steps)
-        return el, mine, [float(k1[i]) for i in range(n)], r
+        spans = []
+        for h in hs:
+            lib.bfa_profile_enable(h, 0)
+            a0 = (ctypes.c_float * max(1, args.steps))()
+            a1 = (ctypes.c_float * max(1, args.steps))()
+            n = lib.bfa_profile_collect_spans(h, ctypes.c_void_p(base.cuda_event), a0, a1, args.steps)
+            spans += [(float(a0[i]), float(a1[i])) for i in range(n)]
+        spans.sort()
+        return el, mine, [b - a for a, b in spans], r, spans
 
     # Window 1: W warm-up steps, then K steps -- the first milliseconds of load.  On MI355X the power management
     # reacts to the load step: K1 starts at its steady duration, rises by ~15 % between ~2 and ~15 ms after the start
@@ -233,9 +261,9 @@ def headline_main(args, rk):
                 step(settle_steps + i)
             settle_steps += 8
             torch.cuda.synchronize()
-        elapsed, mine, k1s, res = timed_window()
+        elapsed, mine, k1s, res, spans = timed_window()
     else:
-        elapsed, mine, k1s, res = first
+        elapsed, mine, k1s, res, spans = first
     nk1 = len(k1s)
     k1_ms = float(np.mean(k1s)) if nk1 > 0 else float("nan")
     if os.environ.get("BFA_BENCH_DUMP_K1"):
@@ -274,7 +302,18 @@ def headline_main(args, rk):
     L = 4 * S + 1
     bytes_per_frame = 4 * C + (L + 3) // 4 + 8
     value = world * frames_per_step * args.steps / elapsed
-    achieved = frames_per_step * bytes_per_frame / (k1_ms * 1e-3) / 1e9 if k1_ms == k1_ms else None
+    # time during which at least one K1 launch was running (union of the launch intervals), per launch
+    busy_ms, cur_a, cur_b = 0.0, None, None
+    for a_, b_ in spans:
+        if cur_b is None or a_ > cur_b:
+            busy_ms += (cur_b - cur_a) if cur_b is not None else 0.0
+            cur_a, cur_b = a_, b_
+        else:
+            cur_b = max(cur_b, b_)
+    busy_ms += (cur_b - cur_a) if cur_b is not None else 0.0
+    busy_per_launch = busy_ms / nk1 if nk1 > 0 else float("nan")
+    achieved = frames_per_step * bytes_per_frame / (busy_per_launch * 1e-3) / 1e9 if nk1 > 0 else None
+    achieved_launch = frames_per_step * bytes_per_frame / (k1_ms * 1e-3) / 1e9 if k1_ms == k1_ms else None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:  # timed at N=1 only
@@ -299,13 +338,24 @@ def headline_main(args, rk):
             "config": {"workload": f"batch={B} T={T} |tokens|={S} ph66 (C={C}) per GPU, reference-default flags "
                                    f"(boost+floor+truly_forced, anchors=10, no SIL in targets -> standard mode)",
                        "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective",
-                       "batches_in_flight": max(1, args.inflight)},
+                       "batches_in_flight": max(1, inflight),
+                       "pipeline": (f"{npipe} decoders taking turns on one stream, walk / run-length encoding of a step on a "
+                                    f"shared tail stream beside the K1 of the next (bfa_set_tail_stream)") if npipe > 1
+                       else "none (stream-ordered calls)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": f"bytes per K1 launch (rocprofv3 PMC, profiles/{tfile})" if tfile else None,
                          "algorithmic_bytes_per_launch": frames_per_step * bytes_per_frame,
                          "kernel": "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer)",
+                         "what": "achieved = algorithmic bytes of a K1 launch / K1 busy time per launch; busy time = union of "
+                                 "the K1 launch intervals in the timed region (HIP events of the library on the launch "
+                                 "streams) -- with one batch in flight it IS the mean launch duration, with several the "
+                                 "launches overlap and share the machine",
+                         "kernel_busy_ms_per_launch": busy_per_launch, "kernel_busy_ms": busy_ms,
+                         "launches_running_on_average": (sum(k1s) / busy_ms) if busy_ms > 0 else None,
                          "kernel_ms": k1_ms, "kernel_ms_stats": _stats(k1s), "kernel_ms_samples": int(nk1),
+                         "achieved_per_launch_duration": achieved_launch,
+                         "frac_per_launch_duration": (achieved_launch / HBM_PEAK_GBS) if achieved_launch else None,
                          "algorithmic_bytes_per_frame": bytes_per_frame,
                          "whole_step_frac": frames_per_step * bytes_per_frame / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
@@ -465,7 +515,7 @@ def c4_main(args, rk):
     # --inflight k: k steps in flight, each on its own stream with its own decoder (workspace) and library handle (aux
     # streams).  A rank's shard of a sharded batch is bound by the chain of its longest utterance, not by the machine;
     # a service that aligns a stream of such batches overlaps them.  `value` stays frames / wall time.
-    nfl = max(1, args.inflight)
+    nfl = max(1, args.inflight or 1)
     aus = [au]
     for k in range(1, nfl):
         a2 = AlignmentUtils(blank_id=blank, silence_id=0)
@@ -662,6 +712,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["headline", "c4"], default="headline")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="headline, experiment (measured: slower than plain calls): n decoders taking turns on one stream "
+                         "with a shared tail stream (bfa_set_tail_stream); 1 = off")
     ap.add_argument("--tlo", type=int, default=200, help="--ragged: shortest utterance")
     ap.add_argument("--thi", type=int, default=3000, help="--ragged: longest utterance")
     ap.add_argument("--batch", type=int, default=4096)
@@ -671,8 +724,9 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=120.0,
                     help="headline: untimed steps run for this long between the first and the reported window (0 = report "
                          "the first window)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="headline: batches in flight (each on its own stream with its own workspace)")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="batches in flight, each on its own stream with its own decoder / library handle / workspace "
+                         "(default: 3 for the headline, 1 for --config c4)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="utterances timed on the host oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-window", action="store_true", help="A/B: full state layout instead of the sliding window")

@@ -18,7 +18,8 @@ MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
            "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
            "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
-           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads"]
+           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_set_tail_stream",
+           "bfa_profile_collect_spans"]
 
 
 class BfaParams(ctypes.Structure):
@@ -84,7 +85,9 @@ def lib():
     L.bfa_align_heads.argtypes = [vp, ctypes.POINTER(BfaHead), i32, i32, i32, vp, vp, vp]
     L.bfa_log_softmax.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
     L.bfa_stitch_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i64, i64, vp]
+    L.bfa_set_tail_stream.argtypes = [vp, vp]
     L.bfa_profile_enable.argtypes = [vp, i32]
+    L.bfa_profile_collect_spans.argtypes = [vp, vp, vp, vp, i32]
     L.bfa_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32]
     _lib = L
     return L

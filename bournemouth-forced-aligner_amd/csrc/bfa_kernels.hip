@@ -313,7 +313,8 @@ extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, in
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void *fork_event, int naux)
+                                void **aux_streams, void **aux_events, void *fork_event, int naux, void *tail_stream,
+                                void *tail_fork_event)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
@@ -372,6 +373,15 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, &fan);
     fan.join();
+    // bfa_set_tail_stream: everything behind K1 (rerun launch, walk, run-length encoding: ~15 % of a headline step, latency
+    // chains that leave the machine mostly idle) goes to the tail stream, so that the caller's stream is free for the K1
+    // of the next call (another handle, another workspace) at once
+    if (tail_stream) {
+        if (ev1) { (void)hipEventRecord((hipEvent_t)ev1, stream); ev1 = nullptr; } // (the K1 bracket ends here)
+        (void)hipEventRecord((hipEvent_t)tail_fork_event, stream);
+        stream = (hipStream_t)tail_stream;
+        (void)hipStreamWaitEvent(stream, (hipEvent_t)tail_fork_event, 0);
+    }
     if (nk <= 2) bfa_launch_dp_redo_nk2(&a, mask, mode, stream);
     else if (nk <= 5) bfa_launch_dp_redo_nk5(&a, mask, mode, stream);
     else bfa_launch_dp_redo_nk8(&a, mask, mode, stream);

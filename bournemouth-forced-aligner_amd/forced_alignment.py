@@ -286,14 +286,25 @@ class ViterbiDecoder:
         return res
 
     def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
-                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
+                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0, tail_stream=None):
         """Whole-batch device call (bfa_align_batch).  Returns an AlignmentResult of device tensors; nothing
-        is synchronised or copied to the host here."""
+        is synchronised or copied to the host here.
+
+        tail_stream (a torch.cuda.Stream): pipelined form (include/bfa.h, bfa_set_tail_stream) -- planning + K1 go to
+        the current stream, the walk / run-length encoding to `tail_stream`, and the current stream does not wait for
+        them: the result tensors are complete on `tail_stream`.  Two decoders (handle_slot 0 / 1: own library handle,
+        workspace and outputs) taking turns keep the K1 of one batch and the tail of the previous one side by side."""
         c = self._prepare_call(log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets, enforce_minimum,
                                anchor_pauses, simple, seg_cap, max_blanks, class_mask)
         dev, lp, T_len = c["dev"], c["lp"], c["T_len"]
         L = _lib.lib()
         h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(), self.handle_slot)
+        tail_ptr = tail_stream.cuda_stream if tail_stream is not None else None
+        if tail_ptr is not None or getattr(self, "_tail_ptr", None) is not None:  # (the handle may be shared: set it per call)
+            rc = L.bfa_set_tail_stream(h, tail_ptr)
+            if rc != 0:
+                raise RuntimeError(f"bfa_set_tail_stream failed ({rc}): {L.bfa_last_error(h).decode()}")
+            self._tail_ptr = tail_ptr
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             rc = L.bfa_align_batch(h, lp.data_ptr(), lp.stride(0), lp.stride(1), c["B"], c["Tmax"], c["C"],
@@ -398,12 +409,13 @@ class AlignmentUtils:
                                               ignore_noise=ignore_noise, truly_forced=self.truly_forced)
 
     def decode_alignments_device(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True,
-                                 enforce_minimum=True, seg_cap=None, class_mask=0):
-        """decode_alignments without the host round trip: returns an AlignmentResult (device tensors)."""
+                                 enforce_minimum=True, seg_cap=None, class_mask=0, tail_stream=None):
+        """decode_alignments without the host round trip: returns an AlignmentResult (device tensors).
+        tail_stream: see ViterbiDecoder.align_batch (pipelined calls)."""
         return self.viterbi_decoder.align_batch(log_probs, true_seqs, pred_lens, true_seqs_lens,
                                                 boost_targets=boost_targets, enforce_minimum=enforce_minimum,
                                                 anchor_pauses=self.silence_anchors > 0, seg_cap=seg_cap,
-                                                class_mask=class_mask)
+                                                class_mask=class_mask, tail_stream=tail_stream)
 
     def decode_alignments(self, log_probs, true_seqs=None, pred_lens=None, true_seqs_lens=None,
                           forced_alignment=True, boost_targets=True, enforce_minimum=True, debug=False):

@@ -12,10 +12,12 @@ from . import _lib
 from .forced_alignment import _as_i32, _device_of
 
 
-def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None, row_stats=None):
+def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None, row_stats=None, handle_slot=0):
     """Batch form: log_probs [B,T,C] (device), segs int32 [B,seg_cap,4], seg_count int32 [B].
     Returns (conf float32 [B,seg_cap], status int32 [B]) as device tensors; no synchronisation.
-    With `row_stats` ([B,T,2] from bfa_align_heads) `log_probs` holds the RAW LOGITS instead."""
+    With `row_stats` ([B,T,2] from bfa_align_heads) `log_probs` holds the RAW LOGITS instead.
+    `handle_slot`: the library handle of the decoder that produced `segs` -- needed when that decoder runs pipelined
+    calls (ViterbiDecoder.align_batch(tail_stream=...)): the pass is then ordered behind the call's pending tail."""
     dev = _device_of(log_probs)
     lp = log_probs.to(device=dev, dtype=torch.float32)
     if lp.stride(2) != 1:
@@ -28,7 +30,7 @@ def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None, row_sta
     conf = torch.zeros((B, seg_cap), dtype=torch.float32, device=dev)
     status = torch.zeros((B,), dtype=torch.int32, device=dev)
     L = _lib.lib()
-    h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+    h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(), handle_slot)
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
         rc = L.bfa_confidences(h, lp.data_ptr(), row_stats.data_ptr() if row_stats is not None else None,

@@ -201,6 +201,20 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
                     const int32_t *S_len, void *stream);
 
 /*
+ * Pipelined calls.  A bfa_align_batch call is planning + K1 (the banded forward pass, ~85 % of a step, which keeps the
+ * machine busy) followed by a tail of latency chains (rerun launch, backtrace, run-length encoding, ~15 %).  With a tail
+ * stream set, a call enqueues planning + K1 on the caller's stream and the tail on `tail_stream` (behind an event);
+ * the caller's stream does NOT wait for the tail, so the K1 of the next call can start while this call's tail runs.
+ * The outputs of a call are complete on the TAIL stream (synchronise on it, or make a consumer stream wait for it;
+ * bfa_confidences / bfa_postprocess / a later bfa_align_* call on the same handle order themselves behind a pending
+ * tail).  A later call on the SAME handle waits for the pending tail before it starts (same workspace): to keep
+ * two calls in flight, alternate between two handles with a workspace and an output set each.  Results are identical
+ * to the stream-ordered form.  tail_stream = NULL restores it.  (bfa_align_heads ignores the tail stream.)
+ * Replaces nothing in the reference: its loop over the batch is sequential (forced_alignment.py:885-905).
+ */
+int bfa_set_tail_stream(bfa_handle h, void *tail_stream);
+
+/*
  * Measurement hooks (bench.py): with on = n >= 1, every n-th bfa_align_batch call brackets its K1 launches
  * (the banded-Viterbi forward kernel) with a pair of HIP events on the caller's stream (n > 1 samples);
  * on = 0 switches it off.
@@ -209,6 +223,13 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
  */
 int bfa_profile_enable(bfa_handle h, int on);
 int bfa_profile_collect(bfa_handle h, float *out_ms_host, int cap);
+/*
+ * The same brackets as intervals: start / end of every recorded K1 bracket in milliseconds after `base_event` (a
+ * timing-enabled hipEvent_t the caller recorded on this device before the calls).  With several calls in flight on
+ * different streams (one handle each) the K1 launches of different calls overlap; the union of the intervals of all
+ * handles is the time the kernel was running at all, which is what a throughput figure has to be priced against.
+ */
+int bfa_profile_collect_spans(bfa_handle h, void *base_event, float *out_start_ms_host, float *out_end_ms_host, int cap);
 
 /*
  * Window stitching, the step in front of the path: stich_window_predictions

@@ -81,3 +81,87 @@ def test_headline_mode_multi_rank_path_on_nccl(gpu_device):
     assert out["n_gpus"] == 1 and out["gather_ms"] is not None and len(out["rank_ms_per_step"]) == 1
     assert out["ranks"][0]["device"] == "cuda:0" and out["value"] > 1e9 and out["roofline"]["frac"] > 0.2
     assert out["settle"]["first_window"]["ms_per_step"] > 0
+
+
+def test_tail_stream_pipeline_is_bitwise_identical(gpu_device):
+    """include/bfa.h bfa_set_tail_stream: two decoders (own handle / workspace / outputs) taking turns on one stream with
+    the walk and the run-length encoding of every call on a shared tail stream.  Every pipelined call must return exactly
+    what the stream-ordered call returns -- standard mode, silence-anchored mode and a mixed-length batch -- and a
+    confidence pass enqueued right behind a pipelined call must see its finished tuples."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from tools.synth import synth_batch, synth_ragged
+    from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch
+    dev = gpu_device
+    work = []
+    for k in range(3):  # standard mode, headline lengths
+        lp, tk = synth_batch(384, 1000, 40, 67, 77 + k, dev)
+        work.append((lp, tk, torch.full((384,), 1000, dtype=torch.int32), torch.full((384,), 40, dtype=torch.int32), 10))
+    lp, tk, Tl, Sl = synth_ragged(256, 200, 1800, 67, 5, dev)  # several K1 classes, window reruns
+    work.append((lp, tk, Tl, Sl, 10))
+    rng = np.random.default_rng(3)  # silence-anchored mode
+    lps, toks = [], []
+    for _ in range(96):
+        a, b, _ = cases.planted_case(rng, 700, 30, C=67, blank=66, peak=9.0, sil_rate=1 / 10, sil_len=(12, 40))
+        lps.append(a); toks.append(b)
+    a, b, Tl2, Sl2 = cases.pad_batch(lps, toks, 67, 66)
+    work.append((torch.from_numpy(a).to(dev), torch.from_numpy(b).to(torch.int32).to(dev),
+                 torch.from_numpy(np.asarray(Tl2, np.int32)), torch.from_numpy(np.asarray(Sl2, np.int32)), 10))
+
+    def fields(r):
+        cnt = r.seg_count.cpu().numpy()
+        segs = r.segs.cpu().numpy()
+        keep = np.arange(segs.shape[1])[None, :] < cnt[:, None]
+        return (cnt, np.where(keep[:, :, None], segs, 0), r.status.cpu().numpy(), r.mode.cpu().numpy(),
+                r.frame_phonemes.cpu().numpy(), r.frame_phonemes_idx.cpu().numpy())
+
+    plain = AlignmentUtils(blank_id=66, silence_id=0)
+    ref = []
+    for lp, tk, Tl, Sl, _ in work:
+        r = plain.decode_alignments_device(lp, tk, Tl.to(dev), Sl.to(dev))
+        cf, _ = calculate_confidences_batch(lp, r.segs, r.seg_count)
+        torch.cuda.synchronize()
+        ref.append(fields(r) + (cf.cpu().numpy(),))
+
+    pipe = [AlignmentUtils(blank_id=66, silence_id=0) for _ in range(2)]
+    for k, x in enumerate(pipe):
+        x.viterbi_decoder.handle_slot = 4 + k
+    tail = torch.cuda.Stream(device=dev)
+    order = [0, 1, 2, 3, 4, 3, 0, 4, 2, 1, 4, 4, 3, 3]
+    got = []
+    for n, w in enumerate(order):  # nothing synchronises inside this loop
+        lp, tk, Tl, Sl, _ = work[w]
+        r = pipe[n % 2].decode_alignments_device(lp, tk, Tl.to(dev), Sl.to(dev), tail_stream=tail)
+        got.append((w, r, None))
+    torch.cuda.synchronize()
+    for w, r, _ in got:
+        for x, y in zip(fields(r), ref[w][:6]):
+            assert np.array_equal(x, y), f"pipelined call on work item {w} differs from the stream-ordered call"
+    # a consumer on the caller's stream right behind a pipelined call (the library orders it behind the pending tail)
+    for n, w in enumerate([0, 4, 3]):
+        lp, tk, Tl, Sl, _ = work[w]
+        au = pipe[n % 2]
+        r = au.decode_alignments_device(lp, tk, Tl.to(dev), Sl.to(dev), tail_stream=tail)
+        cf, _ = calculate_confidences_batch(lp, r.segs, r.seg_count, handle_slot=au.viterbi_decoder.handle_slot)
+        torch.cuda.synchronize()
+        cnt = ref[w][0]
+        keep = np.arange(cf.shape[1])[None, :] < cnt[:, None]
+        assert np.array_equal(np.where(keep, cf.cpu().numpy().view(np.int32), 0), np.where(keep, ref[w][6].view(np.int32), 0))
+
+
+def test_bench_default_keeps_three_batches_in_flight(gpu_device):
+    """`python bench.py` (what the driver runs): three batches in flight on three streams (decoder, library handle and
+    workspace each); the K1 launches overlap, the roofline prices the kernel by its busy time (union of the launch
+    intervals).  With one batch in flight the busy time per launch is the launch duration."""
+    out = _bench_json(["--steps", "20", "--warmup", "5", "--no-cpu", "--settle-ms", "60"])
+    r = out["roofline"]
+    assert out["config"]["batches_in_flight"] == 3 and r["kernel_ms_samples"] == 20
+    assert r["launches_running_on_average"] > 1.2 and r["kernel_busy_ms_per_launch"] < r["kernel_ms"]
+    assert r["kernel_busy_ms_per_launch"] <= out["ms_per_step"] * 1.02  # the kernel cannot be busy longer than the region
+    assert r["frac"] > 0.3 and r["frac_per_launch_duration"] < r["frac"] and out["value"] > 5e9
+    plain = _bench_json(["--steps", "20", "--warmup", "5", "--no-cpu", "--settle-ms", "60", "--inflight", "1"])
+    q = plain["roofline"]
+    assert plain["config"]["batches_in_flight"] == 1 and abs(q["kernel_busy_ms_per_launch"] - q["kernel_ms"]) < 0.02 * q["kernel_ms"]
+    assert abs(q["frac"] - q["frac_per_launch_duration"]) < 0.02
+    print("in flight 3:", out["ms_per_step"], r["kernel_busy_ms_per_launch"], r["kernel_ms"], "| 1:", plain["ms_per_step"], q["kernel_ms"])
