@@ -6,7 +6,10 @@ fused boost/log_softmax/floor + K2 backtrace + run-length encoding) over one bat
 log-probabilities.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-      headline: BASELINE.json configs[2] ("batch=4096 T=1000 |tokens|=40 ph66") PER GPU, weak scaling.
+      headline: BASELINE.json configs[2] ("batch=4096 T=1000 |tokens|=40 ph66") PER GPU, weak scaling.  The K timed
+      steps are issued with three batches in flight (step i on stream i % 3 with its own decoder / library handle /
+      workspace / outputs; --inflight 1 = one batch at a time): the latency-bound tail of a step runs beside the forward
+      kernel of the next ones.  Every step does all of its work inside the timed region; value = frames / wall time.
   python bench.py --config c4 [--gpus N]
       BASELINE.json configs[3]: global B = 32768, T in [200,3000], S = T // 25 (seed 1004), LPT-sharded over the N
       ranks (sharding.shard_utterances), every rank synthesises and aligns only its shard, the result records are
@@ -18,7 +21,8 @@ processes.  `n_gpus` in the JSON line is the world size the process group report
 `--dry-run` does the same launch with the gloo backend and no GPU work (partition + gather plumbing only; CPU test).
 
 One JSON line is printed by rank 0.  `roofline` prices the dominant kernel (K1) with the algorithmic bytes of
-SURVEY.md section 8(d): 4*C + ceil(L/4) + 8 bytes per frame.  `cpu_baseline` times the C restatement of the
+SURVEY.md section 8(d): 4*C + ceil(L/4) + 8 bytes per frame, against the time K1 was running in the timed region
+(union of the K1 launch intervals / launches; = the mean launch duration when one batch is in flight).  `cpu_baseline` times the C restatement of the
 reference (oracle/, kind "port") on the host (N = 1 only).
 """
 import argparse
