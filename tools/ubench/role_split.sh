@@ -14,7 +14,7 @@ done
 wait
 for v in NOPRODUCE NOCONSUME; do
   OBJS=""
-  for f in bfa_kernels.hip bfa_dp_nk2.hip bfa_dp_nk5.hip bfa_dp_nk8.hip bfa_backtrace.hip bfa_segment.hip bfa_post.hip bfa_stitch.hip bfa_capi.cpp; do
+  for f in bfa_kernels.hip bfa_dp_nk5_p3.hip bfa_dp_nk2_p3.hip bfa_dp_nk5_p2.hip bfa_dp_nk2_p2.hip bfa_dp_nk5_p4.hip bfa_dp_nk2_p4.hip bfa_dp_nk5_p5.hip bfa_dp_nk2_p5.hip bfa_dp_nk2.hip bfa_dp_nk5.hip bfa_dp_nk8.hip bfa_backtrace.hip bfa_segment.hip bfa_post.hip bfa_stitch.hip bfa_capi.cpp; do
     if [ "$f" = "bfa_dp_$NK.hip" ]; then OBJS="$OBJS $OUT/${NK}_$v.o"; else OBJS="$OBJS build/$f.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libbfa_${NK}_$v.so $OBJS
