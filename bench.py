@@ -236,6 +236,7 @@ def headline_main(args, rk):
         r = None
         for i in range(args.steps):
             r = step(i)
+        issue = time.perf_counter() - t0  # host time to enqueue the steps (must stay below the device time per step)
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         rk.barrier()
@@ -248,7 +249,7 @@ def headline_main(args, rk):
             n = lib.bfa_profile_collect_spans(h, ctypes.c_void_p(base.cuda_event), a0, a1, args.steps)
             spans += [(float(a0[i]), float(a1[i])) for i in range(n)]
         spans.sort()
-        return el, mine, [b - a for a, b in spans], r, spans
+        return el, mine, [b - a for a, b in spans], r, spans, issue
 
     # Window 1: W warm-up steps, then K steps -- the first milliseconds of load.  On MI355X the power management
     # reacts to the load step: K1 starts at its steady duration, rises by ~15 % between ~2 and ~15 ms after the start
@@ -265,9 +266,9 @@ def headline_main(args, rk):
                 step(settle_steps + i)
             settle_steps += 8
             torch.cuda.synchronize()
-        elapsed, mine, k1s, res, spans = timed_window()
+        elapsed, mine, k1s, res, spans, issue = timed_window()
     else:
-        elapsed, mine, k1s, res, spans = first
+        elapsed, mine, k1s, res, spans, issue = first
     nk1 = len(k1s)
     k1_ms = float(np.mean(k1s)) if nk1 > 0 else float("nan")
     if os.environ.get("BFA_BENCH_DUMP_K1"):
@@ -370,6 +371,7 @@ def headline_main(args, rk):
                                         "ms_per_step": first_elapsed / args.steps * 1e3,
                                         "value": world * frames_per_step * args.steps / first_elapsed,
                                         "kernel_ms_stats": _stats(first[2])}},
+            "host_issue_ms_per_step": issue / args.steps * 1e3,
             "confidence_pass_ms": conf_ms,
             "gather_ms": gather_ms,
             "rank_ms_per_step": rank_ms,
