@@ -1,21 +1,11 @@
 #!/bin/bash
 # Role-time experiment for K1 (producer = softmax wave, consumer = DP wave): builds two extra copies of the
-# library with one role stubbed out (results are wrong, only the kernel time is of interest).
-# Run here (cross-compile), then time on the GPU box with tools/ubench/role_time.py.
+# library with one role stubbed out (results are wrong, only the kernel time is of interest; the sliding-window
+# kernels end early when a stubbed role leaves every window state at the sentinel, so time the full-layout kernels:
+# bench.py --no-window).  Run here (cross-compile), then time on the GPU box with BFA_HIP_LIBRARY=... bench.py.
 set -eu
-cd "$(dirname "$0")/../../bournemouth-forced-aligner_amd/csrc"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I. -I../../include"
-OUT=../../tools/ubench/dbg
-mkdir -p $OUT
 NK=${1:-nk5}   # nk5: the 67-class head, nk2: the 17-class head
+HERE="$(dirname "$0")"
 for v in NOPRODUCE NOCONSUME; do
-  /opt/rocm/bin/hipcc $FLAGS -DBFA_DBG_$v -c bfa_dp_$NK.hip -o $OUT/${NK}_$v.o &
-done
-wait
-for v in NOPRODUCE NOCONSUME; do
-  OBJS=""
-  for f in bfa_kernels.hip bfa_dp_nk5_p3.hip bfa_dp_nk2_p3.hip bfa_dp_nk5_p2.hip bfa_dp_nk2_p2.hip bfa_dp_nk5_p4.hip bfa_dp_nk2_p4.hip bfa_dp_nk5_p5.hip bfa_dp_nk2_p5.hip bfa_dp_nk2.hip bfa_dp_nk5.hip bfa_dp_nk8.hip bfa_backtrace.hip bfa_segment.hip bfa_post.hip bfa_stitch.hip bfa_capi.cpp; do
-    if [ "$f" = "bfa_dp_$NK.hip" ]; then OBJS="$OBJS $OUT/${NK}_$v.o"; else OBJS="$OBJS build/$f.o"; fi
-  done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libbfa_${NK}_$v.so $OBJS
+  bash "$HERE/variant.sh" ${NK}_$v "-DBFA_DBG_$v" bfa_dp_${NK}_p2.hip bfa_dp_${NK}_p3.hip bfa_dp_${NK}_p4.hip bfa_dp_${NK}_p5.hip
 done
