@@ -237,6 +237,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
             const int jl = 63 - __builtin_clzll(mv); // latest frame (lane) at which the path moves
             if (t <= t_hi && lane >= jl) my_state = s;
             const int kk = (int)__builtin_amdgcn_readlane((int)k, jl);
+            const bool at_top = (t0 + jl == t_hi);
             s -= kk;
             if (!WIN) {
                 sr -= kk;
@@ -244,6 +245,28 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
             }
             if (s < 0) { s += L; sl = s / R; sr = s - sl * R; } // python negative-index wrap (:692)
             t_hi = t0 + jl - 1;
+            if (!WIN && at_top && kk == 2 && t_hi >= t0 && s >= 2) {
+                // dense descent (paths below the reference's sentinel step down two states per frame, see
+                // walk_item_mask): lane t looks up its frame's code at the state the path has if it kept descending
+                // by two from the top; the run of "moves by two" below the top is taken in one round
+                const int hi_l = t_hi - t0;
+                const int sp = s - 2 * (hi_l - lane);
+                const bool cand = can_move && lane <= hi_l && sp >= 0;
+                const int spc = cand ? sp : 0;
+                const int pl = spc / R, pr = spc - pl * R, pw = pr >> 2, prs = min(4, R - 4 * pw);
+                const uint32_t wd2 = sbp[rowoff + pw * nl + pl];
+                const uint32_t code2 = (wd2 >> (2 * (4 * prs - 1 - (fw * prs + (pr & 3))))) & 3u;
+                const bool ok = cand && code2 == 3u; // (A << 1) | B: k = 2
+                const unsigned long long oks = __ballot(ok) << (63 - hi_l); // bit 63 = the top frame
+                int run = (~oks == 0ull) ? 64 : __builtin_clzll(~oks);
+                run = min(run, hi_l + 1);
+                if (run > 0) {
+                    if (lane <= hi_l && lane > hi_l - run) my_state = sp;
+                    s -= 2 * run;
+                    sl = s / R; sr = s - sl * R;
+                    t_hi -= run;
+                }
+            }
         }
         int ph = p.blank, id = -1;
         if (mine) {
@@ -281,15 +304,13 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
 {
     constexpr int FPW = (R == 1) ? 16 : (R == 2) ? 8 : 4;
     constexpr int FSH = (FPW == 16) ? 4 : (FPW == 8) ? 3 : 2;
-    // R <= 4: a lane keeps its frame's 2R masks in registers.  Wider layouts: the masks of ONE half of the slots (the
-    // half the walk is in; it changes at most a few times per utterance) are staged in LDS per chunk and a step reads
-    // its pair from there -- instead of a chain of R-1 vector selects per 64-bit mask, and without the register copy
-    // that limited these layouts to one chunk in flight.
+    // R <= 4: a lane keeps its frame's 2R masks in registers.  Wider layouts (the wide walk kernel): the chunk's masks are
+    // staged in LDS, lane = frame, and a step reads its pair from there -- instead of a chain of R-1 vector selects per
+    // 64-bit mask; the registers are free for the next chunk's loads as soon as the chunk is staged.
     constexpr bool STAGE = (R > 4);
     constexpr int NPRE = STAGE ? 2 : 3;                     // chunks in flight in registers (2R qwords per lane each)
     constexpr int NQ = 2 * R;                              // 64-bit masks per frame
-    constexpr int HG = STAGE ? R / 2 : R;                  // slots per staged half
-    constexpr int LSTR = 2 * HG + 1;                       // qwords per lane in LDS (+1: bank spread)
+    constexpr int LSTR = NQ + 1;                           // qwords per lane in LDS (+1: bank spread)
     unsigned long long *sm64 = reinterpret_cast<unsigned long long *>(sbp);
     const DevParams &p = a.p;
     const int b = it.utt;
@@ -329,8 +350,13 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
             for (int q = 0; q < NQ; ++q) mk[q] = buf[q];
         }
         const int wbase = bufb;
-        if (!STAGE) fetch(buf, bufb, c - NPRE); // (STAGE: the registers are needed until the chunk is walked)
-        int staged = -1;                        // STAGE: the half of the slots that is in LDS
+        if (STAGE) {
+            wave_sync_lds(); // the previous chunk's readers are done
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) sm64[lane * LSTR + q] = buf[q];
+            wave_sync_lds();
+        }
+        fetch(buf, bufb, c - NPRE);
         const int t = t0 + lane;
         unsigned long long todo = (n == 64) ? ~0ull : ((1ull << n) - 1ull); // frames the walk has not passed
         if (t0 == 0) todo &= ~1ull;                                          // frame 0 has no predecessor
@@ -354,17 +380,8 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
 #pragma unroll
                 for (int r = 1; r < R; ++r) { if (xr == r) { mA = mk[2 * r]; mB = mk[2 * r + 1]; } }
             } else {
-                const int g = __builtin_amdgcn_readfirstlane(xr / HG); // wave-uniform like the walk state
-                if (g != staged) {
-                    wave_sync_lds();
-#pragma unroll
-                    for (int q = 0; q < 2 * HG; ++q) sm64[lane * LSTR + q] = (g == 0) ? buf[q] : buf[(2 * HG + q) < NQ ? 2 * HG + q : 0];
-                    wave_sync_lds();
-                    staged = g;
-                }
-                const int qq = xr - g * HG;
-                mA = sm64[lane * LSTR + 2 * qq];
-                mB = sm64[lane * LSTR + 2 * qq + 1];
+                mA = sm64[lane * LSTR + 2 * xr];
+                mB = sm64[lane * LSTR + 2 * xr + 1];
             }
             const bool inw = (unsigned)d < (unsigned)(64 * R);
             const unsigned A = inw ? (unsigned)((mA >> xl) & 1ull) : 0u;
@@ -373,12 +390,45 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
             if (lane >= jl && lane <= hi) my_state = s;
             if (mv == 0ull) break; // the path stays in s down to the chunk start
             const unsigned B = (unsigned)((mB >> xl) & 1ull);
-            s -= 1 + (int)__builtin_amdgcn_readlane((int)B, jl); // k = A ? (B ? 2 : 1) : 0
+            const int kmove = 1 + (int)__builtin_amdgcn_readlane((int)B, jl); // k = A ? (B ? 2 : 1) : 0
+            const bool at_top = (jl == hi);
+            s -= kmove;
             if (!WIN && s < 0) s += L;                           // python negative-index wrap (:692)
             hi = jl - 1;
             todo &= (1ull << jl) - 1ull;
+            if constexpr (STAGE && !WIN) {
+                // Dense descent.  Once the path score has crossed the reference's -1000 sentinel (long utterances: more
+                // than ~66 targets) every state is "dead" and the stored backpointers step down two states per frame:
+                // the walk then moves at EVERY frame, one ballot round per frame (8 us per 64-frame chunk).  After a
+                // move by two at the top frame the lanes test the continuation in one round: lane t assumes the path
+                // kept descending by two from the top (state s - 2 (hi - t)) and looks up ITS frame's pair at that state;
+                // the run of lanes below the top that all say "moves by two" is taken at once.
+                if (at_top && kmove == 2 && hi >= 0 && s >= 0) {
+                    const int sp = s - 2 * (hi - lane);
+                    const bool cand = lane <= hi && ((todo >> lane) & 1ull) != 0ull && sp >= 0;
+                    const int spc = cand ? sp : 0;
+                    int pl, pq; // lane and mask slot of the assumed state
+                    if (NC == 1) { pl = spc / R; pq = spc - pl * R; }
+                    else {
+                        constexpr int RS = R / NC;
+                        const int ph = spc / (64 * RS), rem = spc - ph * 64 * RS;
+                        pl = rem / RS;
+                        pq = ph * RS + (rem - pl * RS);
+                    }
+                    const unsigned long long pA = sm64[lane * LSTR + 2 * pq], pB = sm64[lane * LSTR + 2 * pq + 1];
+                    const bool ok = cand && (((pA & pB) >> pl) & 1ull) != 0ull;
+                    const unsigned long long oks = __ballot(ok) << (63 - hi); // bit 63 = the top frame
+                    int run = (~oks == 0ull) ? 64 : __builtin_clzll(~oks);
+                    run = min(run, hi + 1);
+                    if (run > 0) {
+                        if (lane <= hi && lane > hi - run) my_state = sp;
+                        s -= 2 * run;
+                        hi -= run;
+                        todo &= (hi >= 0) ? ((2ull << hi) - 1ull) : 0ull;
+                    }
+                }
+            }
         }
-        if (STAGE) fetch(buf, bufb, c - NPRE); // behind the walk: its loads overlap the stores below and the next chunk
         int ph = p.blank, id = -1;
         if (lane < n) {
             const int o = t - it.pad_left; // :447-448 trim the boundary padding
@@ -616,7 +666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 
 __global__ __launch_bounds__(64) void k_backtrace_wide(AlignArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t sbp[18 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t sbp[2 * 33 * 64]; // a chunk's 2R lane masks per frame, R <= 16 (+1 qword: bank spread)
     __shared__ int32_t stok[1024];
     backtrace_body<true>(a, sbp, stok);
 }
