@@ -527,10 +527,16 @@ __device__ __forceinline__ void walk_item_big(const AlignArgs &a, const Item &it
 //   K2_FULL + R     full-layout DPs of class R that a K1 kernel has finished
 //   K2_BIG          paths of more than 1024 states
 //   K2_REST         everything the two above never take: non-DP items, window items, rerun items, items no K1 kernel took
+//   K2_WIN          window items whose window kernel succeeded (launched behind the window kernels on their stream);
+//   K2_REST_NOWIN   K2_REST without those
 __device__ __forceinline__ bool k2_selected(int sel, const Item &it)
 {
     if (sel == K2_ALL) return true;
     const bool plain_full = it.kind == ITEM_DP && it.win == 0 && it.final_state != FINAL_NOT_COMPUTED;
+    // a window item whose window kernel ended above the sentinel (the others are rerun with the full layout: win < 0)
+    const bool window_done = it.kind == ITEM_DP && it.win > 0 && it.final_state != FINAL_NOT_COMPUTED;
+    if (sel == K2_WIN) return window_done;
+    if (sel == K2_REST_NOWIN) return !plain_full && !window_done;
     if (sel == K2_REST) return !plain_full;
     if (!plain_full) return false;
     if (sel == K2_BIG) return it.L > 1024;

@@ -361,6 +361,9 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     fan.forked = (hipEvent_t)fork_event;
     fan.naux = (n_kernels > 1 && aux_streams) ? naux : 0;
     fan.used = 0;
+    // several K1 kernels side by side: the window items are walked on the window kernels' stream as soon as those are
+    // done (with ONE kernel -- the headline batch -- that would only add a launch to the serial chain)
+    a.k2_windows = (per_class_k2 && fan.naux > 0 && wmask != 0) ? 1 : 0;
     if (Lmax > 1024) { // paths of more than 1024 states can occur: the workgroup-wide kernel takes them
         const int big_grid = a.B < 1024 ? a.B : 1024;
         hipStream_t bs = fan.pick();
@@ -392,7 +395,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (per_class_k2) {
         // window / rerun items, fills, items nobody took: wide only if a window item (or its full-layout rerun) can be
         const bool rest_wide = (mask & (0xa0u << 8)) != 0 || (wmask != 0 && Lmax > 256);
-        bfa_launch_backtrace_sel(&a, K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
+        bfa_launch_backtrace_sel(&a, a.k2_windows ? K2_REST_NOWIN : K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
         if (!fused_k2) hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     } else {
         static const int k2_env = [] { const char *e = getenv("BFA_K2_GRID"); return e ? atoi(e) : 0; }(); // (measurement switch)
