@@ -385,7 +385,9 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         stream = (hipStream_t)tail_stream;
         (void)hipStreamWaitEvent(stream, (hipEvent_t)tail_fork_event, 0);
     }
-    if (nk <= 2) bfa_launch_dp_redo_nk2(&a, mask, mode, stream);
+    const bool redo_done = a.k2_windows && (a.C == 67 || a.C == 17); // (launched behind the window kernels on their stream, bfa_dp3.inc)
+    if (redo_done) { /* nothing */ }
+    else if (nk <= 2) bfa_launch_dp_redo_nk2(&a, mask, mode, stream);
     else if (nk <= 5) bfa_launch_dp_redo_nk5(&a, mask, mode, stream);
     else bfa_launch_dp_redo_nk8(&a, mask, mode, stream);
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);

@@ -9,4 +9,4 @@ done
 python bench.py --config c4 --steps 6 --parity-sample 256 2>/dev/null | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   c4 N=1 ms', round(d['ms_per_step'],3), d['parity_sample']['mismatching_utterances'])"
 python bench.py --no-cpu --steps 20 --warmup 5 | python tools/ubench/extract.py /dev/stdin
 python bench.py --no-cpu --steps 20 --warmup 5 --inflight 1 | python tools/ubench/extract.py /dev/stdin
-bash tools/r2_ragprof.sh 2>&1 | tail -22
+bash tools/r2_ragprof.sh 2>&1 | tail -8
