@@ -165,3 +165,48 @@ def test_bench_default_keeps_three_batches_in_flight(gpu_device):
     assert plain["config"]["batches_in_flight"] == 1 and abs(q["kernel_busy_ms_per_launch"] - q["kernel_ms"]) < 0.02 * q["kernel_ms"]
     assert abs(q["frac"] - q["frac_per_launch_duration"]) < 0.02
     print("in flight 3:", out["ms_per_step"], r["kernel_busy_ms_per_launch"], r["kernel_ms"], "| 1:", plain["ms_per_step"], q["kernel_ms"])
+
+
+def test_batches_in_flight_helper_matches_plain_calls(gpu_device):
+    """bournemouth_forced_aligner_amd.BatchesInFlight (what bench.py times): three decoders / streams taking turns; every
+    result must equal the plain call's, and `result.wait()` must order a consumer on the caller's stream behind it."""
+    sys.path.insert(0, ROOT)
+    from tools.synth import synth_batch, synth_ragged
+    from bournemouth_forced_aligner_amd import AlignmentUtils, BatchesInFlight, calculate_confidences_batch
+    dev = gpu_device
+    work = [synth_batch(512, 1000, 40, 67, 300 + k, dev) + (None, None) for k in range(4)]
+    lp, tk, Tl, Sl = synth_ragged(192, 200, 2600, 67, 9, dev)
+    work.append((lp, tk, Tl.to(dev), Sl.to(dev)))
+    plain = AlignmentUtils(blank_id=66, silence_id=0)
+
+    def lens(w):
+        lp, tk, Tl, Sl = w
+        if Tl is None:
+            Tl = torch.full((lp.shape[0],), lp.shape[1], dtype=torch.int32, device=dev)
+            Sl = torch.full((lp.shape[0],), tk.shape[1], dtype=torch.int32, device=dev)
+        return lp, tk, Tl, Sl
+
+    ref = []
+    for w in work:
+        lp, tk, Tl, Sl = lens(w)
+        r = plain.decode_alignments_device(lp, tk, Tl, Sl)
+        cf, _ = calculate_confidences_batch(lp, r.segs, r.seg_count)
+        torch.cuda.synchronize()
+        ref.append((r.seg_count.cpu().numpy(), r.segs.cpu().numpy(), r.frame_phonemes.cpu().numpy(), cf.cpu().numpy()))
+    bif = BatchesInFlight(66, 0, n=3, device=dev, first_handle_slot=8)
+    got = []
+    for n in range(11):
+        lp, tk, Tl, Sl = lens(work[n % len(work)])
+        r = bif.submit(lp, tk, Tl, Sl)
+        r.wait()  # the confidence pass below runs on the caller's stream
+        cf, _ = calculate_confidences_batch(lp, r.segs, r.seg_count)
+        got.append((n % len(work), r, cf))
+    bif.synchronize()
+    torch.cuda.synchronize()
+    for w, r, cf in got:
+        cnt, segs, fph, rcf = ref[w]
+        keep = np.arange(segs.shape[1])[None, :] < cnt[:, None]
+        assert np.array_equal(r.seg_count.cpu().numpy(), cnt)
+        assert np.array_equal(np.where(keep[:, :, None], r.segs.cpu().numpy(), 0), np.where(keep[:, :, None], segs, 0))
+        assert np.array_equal(r.frame_phonemes.cpu().numpy(), fph)
+        assert np.array_equal(np.where(keep, cf.cpu().numpy().view(np.int32), 0), np.where(keep, rcf.view(np.int32), 0))
