@@ -34,17 +34,24 @@ tkd = tkd.to(dev).to(torch.int32)
 Td = torch.from_numpy(Tl.astype(np.int32)).to(dev)
 Sd = torch.from_numpy(Sl.astype(np.int32)).to(dev)
 N = int(os.environ.get("BFA_SIL_STEPS", "50"))
-for _ in range(5):
-    res = au.decode_alignments_device(lpd, tkd, Td, Sd, class_mask=hint)
+NFL = int(os.environ.get("BFA_SIL_INFLIGHT", "1"))  # batches in flight (BatchesInFlight), 1 = plain calls
+if NFL > 1:
+    from bournemouth_forced_aligner_amd import BatchesInFlight
+    bif = BatchesInFlight(blank, 0, n=NFL, device=dev, wait_for_caller=False)
+    call = lambda: bif.submit(lpd, tkd, Td, Sd, class_mask=hint)
+else:
+    call = lambda: au.decode_alignments_device(lpd, tkd, Td, Sd, class_mask=hint)
+for _ in range(6):
+    res = call()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(N):
-    res = au.decode_alignments_device(lpd, tkd, Td, Sd, class_mask=hint)
+    res = call()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / N * 1e3
 md = res.mode.cpu().numpy()
 exp = ora.decode_alignments(lp[:64], tk[:64], T_len[:64], S_len[:64], ora.make_params(blank, 0), seg_cap=res.segs.shape[1])
 gs, gc = res.segs[:64].cpu().numpy(), res.seg_count[:64].cpu().numpy()
 mism = sum(int(gc[b] != exp["seg_count"][b] or not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all()) for b in range(64))
-print(f"B={NB * rep} T={T} S={S} with SIL: {ms:.3f} ms per step = {NB * rep * T / ms / 1e6:.2f} G frames/s; "
+print(f"B={NB * rep} T={T} S={S} with SIL, {NFL} in flight: {ms:.3f} ms per step = {NB * rep * T / ms / 1e6:.2f} G frames/s; "
       f"segmented utterances {int((md == 1).sum())}/{len(md)}; parity sample mismatches {mism}/64")
