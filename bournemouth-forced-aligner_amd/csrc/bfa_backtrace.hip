@@ -644,8 +644,12 @@ __device__ __forceinline__ void backtrace_body(const AlignArgs &a, uint32_t *sbp
                 default: walk_item<4, false>(a, it, sbp, stok, lane, rle, do_rle); break;
                 }
             } else if (it.split == 2) { // K1 split the DP over two consumer waves: per-frame lane masks (bfa_dp5.inc)
-                if (r_class_for_L(it.L) == 6) walk_item_mask<6, false, 2>(a, it, sbp, stok, lane, rle, do_rle);
-                else walk_item_mask<8, false, 2>(a, it, sbp, stok, lane, rle, do_rle);
+                switch (r_class_for_L(it.L)) {
+                case 6: walk_item_mask<6, false, 2>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 8: walk_item_mask<8, false, 2>(a, it, sbp, stok, lane, rle, do_rle); break;
+                case 12: walk_item_mask<12, false, 2>(a, it, sbp, stok, lane, rle, do_rle); break;
+                default: walk_item_mask<16, false, 2>(a, it, sbp, stok, lane, rle, do_rle); break;
+                }
             } else {
                 switch (it.L > 1024 ? 0 : r_class_for_L(it.L)) {
                 case 6: walk_item<6, false>(a, it, sbp, stok, lane, rle, do_rle); break;
