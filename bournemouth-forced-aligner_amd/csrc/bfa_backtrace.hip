@@ -650,6 +650,9 @@ __device__ __forceinline__ void backtrace_body(const AlignArgs &a, uint32_t *sbp
                 case 12: walk_item_mask<12, false, 2>(a, it, sbp, stok, lane, rle, do_rle); break;
                 default: walk_item_mask<16, false, 2>(a, it, sbp, stok, lane, rle, do_rle); break;
                 }
+            } else if (it.split == 4) { // four consumer waves (BFA_NC8 = 4)
+                if (r_class_for_L(it.L) == 8) walk_item_mask<8, false, 4>(a, it, sbp, stok, lane, rle, do_rle);
+                else walk_item_mask<16, false, 4>(a, it, sbp, stok, lane, rle, do_rle);
             } else {
                 switch (it.L > 1024 ? 0 : r_class_for_L(it.L)) {
                 case 6: walk_item<6, false>(a, it, sbp, stok, lane, rle, do_rle); break;
