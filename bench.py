@@ -20,10 +20,20 @@ environment; started directly with --gpus N > 1 the script re-executes itself un
 processes.  `n_gpus` in the JSON line is the world size the process group reports, `ranks` lists the device of each.
 `--dry-run` does the same launch with the gloo backend and no GPU work (partition + gather plumbing only; CPU test).
 
+  python bench.py --config realtext
+      the path real transcripts take: raw logits of both heads, SIL in the targets (silence-anchored mode),
+      bfa_align_heads + bfa_postprocess + bfa_confidences per step; 512-utterance oracle parity count in the line.
+
+Timing protocol: W warm-up steps, then ceil(100 / K) windows of EXACTLY K steps, each bracketed by barrier +
+synchronize on both sides, max over ranks; `value` = frames of all windows / sum of the window times.  Everything that
+ran before the reported windows (warm-up, the first window -- reported separately --, the --settle-ms steps) is counted
+in `timing.warmup_effective_steps`.
+
 One JSON line is printed by rank 0.  `roofline` prices the dominant kernel (K1) with the algorithmic bytes of
-SURVEY.md section 8(d): 4*C + ceil(L/4) + 8 bytes per frame, against the time K1 was running in the timed region
-(union of the K1 launch intervals / launches; = the mean launch duration when one batch is in flight).  `cpu_baseline` times the C restatement of the
-reference (oracle/, kind "port") on the host (N = 1 only).
+SURVEY.md section 8(d): 4*C + ceil(L/4) + 8 bytes per frame, against K1's mean launch duration in a leg of the same
+run with ONE batch in flight (no launch overlaps another), which is what `rocprofv3 --kernel-trace --stats` of
+`python bench.py --inflight 1` reports for the kernel.  `cpu_baseline` times the C restatement of the reference
+(oracle/, kind "port") on the host (N = 1 only).
 """
 import argparse
 import ctypes
@@ -158,133 +168,162 @@ def _reference_cpu_record():
 
 
 # --------------------------------------------------------------------------------------------- headline
+def _timed_windows(rk, run_steps, K, n_windows):
+    """n_windows windows of EXACTLY K steps each, every window bracketed by barrier + synchronize on both sides; the
+    window time is the max over ranks.  Returns (list of window seconds, list of host issue seconds)."""
+    times, issues = [], []
+    for _ in range(n_windows):
+        rk.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(K)
+        issues.append(time.perf_counter() - t0)  # host time to enqueue the steps (must stay below the device time)
+        torch.cuda.synchronize()
+        rk.barrier()
+        el, _ = rk.max_over_ranks(time.perf_counter() - t0)
+        times.append(el)
+    return times, issues
+
+
+def _union_ms(spans):
+    """total length of the union of (start, end) intervals"""
+    busy, cur_a, cur_b = 0.0, None, None
+    for a_, b_ in sorted(spans):
+        if cur_b is None or a_ > cur_b:
+            busy += (cur_b - cur_a) if cur_b is not None else 0.0
+            cur_a, cur_b = a_, b_
+        else:
+            cur_b = max(cur_b, b_)
+    return busy + ((cur_b - cur_a) if cur_b is not None else 0.0)
+
+
 def headline_main(args, rk):
-    from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch, _lib
+    from bournemouth_forced_aligner_amd import BatchesInFlight, calculate_confidences_batch, _lib
     from bournemouth_forced_aligner_amd.sharding import gather_results
     dev, rank, world, dist = rk.dev, rk.rank, rk.world, rk.dist
     B, T, S, C = args.batch, args.frames, args.tokens, args.classes
     blank, sil = C - 1, 0
-    # --pipeline n >= 2 (default 2): n decoders (own library handle, workspace, outputs) take turns on ONE stream and share
-    # a tail stream (include/bfa.h, bfa_set_tail_stream): planning + K1 of step i+1 start as soon as K1 of step i has
-    # ended, while the walk / run-length encoding of step i runs beside them.  --inflight n is the older form (whole steps
-    # on n streams: their K1 kernels overlap each other and a launch's duration stops being a measure of the kernel).
+    K = args.steps
     # Batches in flight (default 3): step i runs on stream i % 3 with decoder i % 3 (own library handle, workspace and
     # outputs), so the tail of a step (rerun launch, walk, run-length encoding: ~65 us of latency chains that leave the
-    # machine mostly idle) and the ramp-down of its K1 overlap the K1 of the next steps.  `value` stays frames / wall time.
-    # The K1 launches of different steps then overlap each other: a launch's own duration (kernel_ms) is no longer the
-    # time the kernel needs for a batch, so the roofline prices the kernel by the time it was running AT ALL -- the union
-    # of the launch intervals (bfa_profile_collect_spans) -- see `roofline` below.
-    inflight = args.inflight if args.inflight is not None else 3
-    npipe = args.pipeline if (inflight <= 1 and args.pipeline > 1) else 1
-    nbuf = max(2, inflight, npipe)
+    # machine mostly idle) and the ramp-down of its K1 overlap the K1 of the next steps.  `value` = frames / wall time.
+    # The K1 launches of different steps then overlap each other, so a launch's duration there says how long it SHARED
+    # the machine: the roofline entry is priced by a separate leg of this same run with ONE batch in flight (below).
+    inflight = max(1, args.inflight if args.inflight is not None else 3)
+    nbuf = max(2, inflight)
     # distinct batches so consecutive steps never stream the same 1.1 GB (> the 256 MB Infinity Cache anyway)
     bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
     if os.environ.get("BFA_BENCH_SAME_INPUT"):  # (experiment: every utterance reads utterance 0 -> cache-resident rows)
         bufs = [(lp[:1].expand(B, T, C), tk[:1].expand(B, S).contiguous()) for lp, tk in bufs]
+    if args.row_pitch:  # A/B (SURVEY 8(f)-3): the same log-probs in rows padded to `row_pitch` floats (e.g. 72 = 288 B)
+        assert args.row_pitch >= C
+        padded = []
+        for lp, tk in bufs:
+            wide = torch.zeros((B, T, args.row_pitch), dtype=torch.float32, device=dev)
+            wide[:, :, :C] = lp
+            padded.append((wide[:, :, :C], tk))  # a [B,T,C] view with row stride `row_pitch`
+        bufs = padded
     T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
     S_len = torch.full((B,), S, dtype=torch.int32, device=dev)
-    # reference defaults: anchors 10, boost, floor, truly_forced.  One decoder (= one workspace) per batch in flight.
-    from bournemouth_forced_aligner_amd import BatchesInFlight
-    # the product's own helper (inflight.py); the batches are resident and complete before the timed region starts
-    bif = BatchesInFlight(blank, sil, n=max(1, inflight, npipe), device=dev,
+    # the product's own helper (inflight.py): one decoder (= library handle, workspace, outputs) per batch in flight;
+    # reference defaults: anchors 10, boost, floor, truly_forced.  The batches are resident before the timed region.
+    bif = BatchesInFlight(blank, sil, n=inflight, device=dev,
                           wait_for_caller=bool(int(os.environ.get("BFA_BENCH_WAIT_CALLER", "0"))))
     aus = bif.decoders
     au = aus[0]
     lib = _lib.lib()
     hs = [_lib.handle(rk.local_rank, k) for k in range(len(aus))]
-    # (a stream of its own priority gets a hardware queue of its own; streams of one priority share a few queues, and a tail
-    # stream that lands on the queue of the launch stream would run in submission order behind the next K1)
-    tail_prio = int(os.environ.get("BFA_BENCH_TAIL_PRIO", "-1"))
-    tail = torch.cuda.Stream(device=dev, priority=tail_prio) if npipe > 1 else None
-
     # the lengths are known on the host (constant here), and the synthetic targets never contain SIL:
     # tell the library which K1 register class occurs so that it does not launch the empty ones
     hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False, n_classes=(None if args.no_window else C))
-
-    streams = bif.streams if (inflight > 1 and npipe == 1) else None
+    counter = [0]
+    last = [None]
 
     def step(i):
         lp, tk = bufs[i % nbuf]
-        if tail is not None:
-            return aus[i % npipe].decode_alignments_device(lp, tk, T_len, S_len, class_mask=hint, tail_stream=tail)
-        if streams is None:
+        if inflight <= 1:
             return au.decode_alignments_device(lp, tk, T_len, S_len, class_mask=hint)
-        # batches i, i+1, i+2 on different streams with their own decoders: the latency-bound tail of one (backtrace,
-        # run-length encoding) and the ramp-down of its K1 overlap the K1 of the next ones
         return bif.submit(lp, tk, T_len, S_len, class_mask=hint)
 
-    res = None
-    for i in range(args.warmup):
-        res = step(i)
-    torch.cuda.synchronize()
+    def run_steps(n):
+        for _ in range(n):
+            last[0] = step(counter[0])
+            counter[0] += 1
 
     def check_status(r):
         if r is not None and not os.environ.get("BFA_HIP_LIBRARY"):  # (kernel-time experiments with a stubbed role produce garbage)
             st = r.status.cpu().numpy()
             assert (st == 0).all(), f"alignment failed on the bench workload: {np.unique(st)}"
-    check_status(res)
 
-    # K1 of every step is bracketed with HIP events on the launch stream (measured: no effect on the step time;
-    # BFA_BENCH_K1_EVERY=n samples every n-th step instead)
-    k1_every = int(os.environ.get("BFA_BENCH_K1_EVERY", "1"))
-
-    def timed_window():
-        """EXACTLY args.steps steps between barrier + synchronize on both sides; K1 events collected."""
-        for h in hs:
-            lib.bfa_profile_enable(h, k1_every)
-        rk.barrier()
-        torch.cuda.synchronize()
-        base = torch.cuda.Event(enable_timing=True)
-        base.record()
-        t0 = time.perf_counter()
-        r = None
-        for i in range(args.steps):
-            r = step(i)
-        issue = time.perf_counter() - t0  # host time to enqueue the steps (must stay below the device time per step)
-        torch.cuda.synchronize()
-        mine = time.perf_counter() - t0
-        rk.barrier()
-        el = time.perf_counter() - t0
-        spans = []
-        for h in hs:
-            lib.bfa_profile_enable(h, 0)
-            a0 = (ctypes.c_float * max(1, args.steps))()
-            a1 = (ctypes.c_float * max(1, args.steps))()
-            n = lib.bfa_profile_collect_spans(h, ctypes.c_void_p(base.cuda_event), a0, a1, args.steps)
-            spans += [(float(a0[i]), float(a1[i])) for i in range(n)]
-        spans.sort()
-        return el, mine, [b - a for a, b in spans], r, spans, issue
-
-    # Window 1: W warm-up steps, then K steps -- the first milliseconds of load.  On MI355X the power management
-    # reacts to the load step: K1 starts at its steady duration, rises by ~15 % between ~2 and ~15 ms after the start
-    # and settles back after ~30-50 ms (profiles/r02_k1_series.txt); a 20-step window right after 5 warm-up steps lands
-    # exactly in that transient.  So the steps are then kept running, untimed, for --settle-ms, and window 2 (again
-    # EXACTLY K steps, same barriers) measures the settled state.  `value` is window 2; window 1 is reported beside it.
-    first = timed_window()
+    # ---- W untimed warm-up steps
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    check_status(last[0])
+    # ---- window 0: the K steps right behind the W warm-up steps, i.e. the first milliseconds of load.  The power management
+    # reacts to the load step: K1 starts at its steady duration, rises by ~15 % between ~2 and ~15 ms and settles after
+    # ~30-50 ms (profiles/r02_k1_series.txt).  It is REPORTED (`first_window`) but is not `value`: the steps then keep
+    # running, untimed, for --settle-ms; everything that ran before the reported windows is counted in
+    # `warmup_effective_steps`.
+    first_t, _ = _timed_windows(rk, run_steps, K, 1)
     settle_steps = 0
     if args.settle_ms > 0:
-        torch.cuda.synchronize()
         s0 = time.perf_counter()
         while (time.perf_counter() - s0) * 1e3 < args.settle_ms:
-            for i in range(8):
-                step(settle_steps + i)
+            run_steps(8)
             settle_steps += 8
             torch.cuda.synchronize()
-        elapsed, mine, k1s, res, spans, issue = timed_window()
-    else:
-        elapsed, mine, k1s, res, spans, issue = first
-    check_status(res)
-    nk1 = len(k1s)
-    k1_ms = float(np.mean(k1s)) if nk1 > 0 else float("nan")
+    warm_eff = counter[0]
+    # ---- the reported windows: ceil(min_timed_steps / K) windows of EXACTLY K steps each (SURVEY.md 8(d): >= 100
+    # back-to-back iterations); K1 of every step bracketed with HIP events on its launch stream (measured: no effect)
+    n_windows = max(1, -(-args.min_timed_steps // K))
+    k1_every = int(os.environ.get("BFA_BENCH_K1_EVERY", "1"))
+    for h in hs:
+        lib.bfa_profile_enable(h, k1_every)
+    torch.cuda.synchronize()
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
+    win_t, issue_t = _timed_windows(rk, run_steps, K, n_windows)
+    spans = []
+    cap = K * n_windows + 8
+    for h in hs:
+        lib.bfa_profile_enable(h, 0)
+        a0 = (ctypes.c_float * cap)()
+        a1 = (ctypes.c_float * cap)()
+        n = lib.bfa_profile_collect_spans(h, ctypes.c_void_p(base.cuda_event), a0, a1, cap)
+        spans += [(float(a0[i]), float(a1[i])) for i in range(n)]
+    check_status(last[0])
+    res = last[0]
+    total_steps = K * n_windows
+    elapsed = float(np.sum(win_t))
+    win_ms = [t / K * 1e3 for t in win_t]
+    k1_inflight = [b - a for a, b in spans]
+    busy_ms = _union_ms(spans)
     if os.environ.get("BFA_BENCH_DUMP_K1"):
-        print("k1 series (ms), first window:", " ".join(f"{v:.3f}" for v in first[2]), file=sys.stderr)
-        print("k1 series (ms), settled window:", " ".join(f"{v:.3f}" for v in k1s), file=sys.stderr)
-    elapsed, _ = rk.max_over_ranks(elapsed)
-    first_elapsed, _ = rk.max_over_ranks(first[0])
-    _, rank_ms = rk.max_over_ranks(mine / args.steps * 1e3)
+        print("k1 series (ms), reported windows:", " ".join(f"{v:.3f}" for v in k1_inflight), file=sys.stderr)
+
+    # ---- the kernel leg: the SAME steps with ONE batch in flight (plain stream-ordered calls on the caller's stream), K1
+    # bracketed by HIP events on that stream.  Nothing overlaps a K1 launch here, so its mean duration is what
+    # `rocprofv3 --kernel-trace --stats -- python bench.py --inflight 1` reports for the kernel
+    # (profiles/r03_headline_inflight1_kernel_stats.csv), and roofline.achieved = algorithmic bytes / that mean.
+    n_leg = max(20, min(args.kernel_leg_steps, 400))
+    torch.cuda.synchronize()
+    for i in range(4):
+        au.decode_alignments_device(*bufs[i % nbuf], T_len, S_len, class_mask=hint)
+    torch.cuda.synchronize()
+    lib.bfa_profile_enable(hs[0], 1)
+    l0 = time.perf_counter()
+    for i in range(n_leg):
+        au.decode_alignments_device(*bufs[i % nbuf], T_len, S_len, class_mask=hint)
+    torch.cuda.synchronize()
+    leg_ms = (time.perf_counter() - l0) / n_leg * 1e3
+    lib.bfa_profile_enable(hs[0], 0)
+    kbuf = (ctypes.c_float * n_leg)()
+    nk = lib.bfa_profile_collect(hs[0], kbuf, n_leg)
+    k1_alone = [float(kbuf[i]) for i in range(nk)]
+    kernel_ms = float(np.mean(k1_alone)) if nk else float("nan")
 
     # confidence pass (utils._calculate_confidences), timed separately: it is a separate reference call
-    lp0, _ = bufs[(args.steps - 1) % nbuf]
+    lp0, _ = bufs[(counter[0] - 1) % nbuf]
     torch.cuda.synchronize()
     c0 = time.perf_counter()
     for _ in range(5):
@@ -311,75 +350,74 @@ def headline_main(args, rk):
     frames_per_step = B * T
     L = 4 * S + 1
     bytes_per_frame = 4 * C + (L + 3) // 4 + 8
-    value = world * frames_per_step * args.steps / elapsed
-    # time during which at least one K1 launch was running (union of the launch intervals), per launch
-    busy_ms, cur_a, cur_b = 0.0, None, None
-    for a_, b_ in spans:
-        if cur_b is None or a_ > cur_b:
-            busy_ms += (cur_b - cur_a) if cur_b is not None else 0.0
-            cur_a, cur_b = a_, b_
-        else:
-            cur_b = max(cur_b, b_)
-    busy_ms += (cur_b - cur_a) if cur_b is not None else 0.0
-    busy_per_launch = busy_ms / nk1 if nk1 > 0 else float("nan")
-    achieved = frames_per_step * bytes_per_frame / (busy_per_launch * 1e-3) / 1e9 if nk1 > 0 else None
-    achieved_launch = frames_per_step * bytes_per_frame / (k1_ms * 1e-3) / 1e9 if k1_ms == k1_ms else None
+    alg_bytes = frames_per_step * bytes_per_frame
+    value = world * frames_per_step * total_steps / elapsed
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if nk else None
+    busy_per_launch = busy_ms / len(spans) if spans else None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:  # timed at N=1 only
-        cpu = cpu_baseline_leg(args, bufs, step, B, T, S, C, blank, sil)
+        cpu = cpu_baseline_leg(args, bufs, lambda i: au.decode_alignments_device(*bufs[i % nbuf], T_len, S_len, class_mask=hint),
+                               B, T, S, C, blank, sil)
 
     # HBM bytes of one K1 launch from the PMC passes of tools/profile.sh (committed under profiles/), if it was
     # taken on this workload; FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes
     traffic, tfile = None, None
-    for name in ("r02_k1_traffic.json", "r01_k1_traffic.json"):
+    for name in ("r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath) and (B, T, S, C) == (4096, 1000, 40, 67):
+        if os.path.exists(tpath) and (B, T, S, C) == (4096, 1000, 40, 67) and not args.row_pitch:
             traffic, tfile = json.load(open(tpath))["traffic_bytes_per_launch"], name
             break
 
     ranks = rk.describe()
     if rank == 0:
+        kname = "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer)" if (B, T, S, C) == (4096, 1000, 40, 67) \
+            else "K1 banded Viterbi forward (class kernel of this shape)"
         line = {
             "metric": "aligned frames/sec (whole node) on ph66 posteriors", "value": value,
-            "unit": "aligned frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "unit": "aligned frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch={B} T={T} |tokens|={S} ph66 (C={C}) per GPU, reference-default flags "
                                    f"(boost+floor+truly_forced, anchors=10, no SIL in targets -> standard mode)",
                        "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective",
-                       "batches_in_flight": max(1, inflight),
-                       "pipeline": (f"{npipe} decoders taking turns on one stream, walk / run-length encoding of a step on a "
-                                    f"shared tail stream beside the K1 of the next (bfa_set_tail_stream)") if npipe > 1
-                       else "none (stream-ordered calls)"},
+                       "batches_in_flight": inflight, "row_pitch_floats": args.row_pitch or C},
+            "timing": {"what": f"{n_windows} windows of exactly {K} steps, each bracketed by barrier + synchronize on both "
+                               f"sides (max over ranks); value = frames of all windows / sum of the window times",
+                       "windows": n_windows, "timed_steps_total": total_steps,
+                       "window_ms_per_step": {"mean": float(np.mean(win_ms)), "min": float(np.min(win_ms)),
+                                              "max": float(np.max(win_ms)), "all": win_ms},
+                       "warmup_requested_steps": args.warmup, "warmup_effective_steps": warm_eff,
+                       "warmup_effective_what": f"{args.warmup} warm-up steps + the first window ({K} steps, reported below) + "
+                                                f"{settle_steps} untimed steps over --settle-ms {args.settle_ms:g}",
+                       "first_window": {"what": f"the {K} steps right after the {args.warmup} warm-up steps (power-management "
+                                                "transient of the first ~30 ms of load)",
+                                        "ms_per_step": first_t[0] / K * 1e3,
+                                        "value": world * frames_per_step * K / first_t[0]},
+                       "host_issue_ms_per_step": float(np.sum(issue_t)) / total_steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_unit": f"bytes per K1 launch (rocprofv3 PMC, profiles/{tfile})" if tfile else None,
-                         "algorithmic_bytes_per_launch": frames_per_step * bytes_per_frame,
-                         "kernel": "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer)",
-                         "what": "achieved = algorithmic bytes of a K1 launch / K1 busy time per launch; busy time = union of "
-                                 "the K1 launch intervals in the timed region (HIP events of the library on the launch "
-                                 "streams) -- with one batch in flight it IS the mean launch duration, with several the "
-                                 "launches overlap and share the machine",
-                         "kernel_busy_ms_per_launch": busy_per_launch, "kernel_busy_ms": busy_ms,
-                         "launches_running_on_average": (sum(k1s) / busy_ms) if busy_ms > 0 else None,
-                         "kernel_ms": k1_ms, "kernel_ms_stats": _stats(k1s), "kernel_ms_samples": int(nk1),
-                         "achieved_per_launch_duration": achieved_launch,
-                         "frac_per_launch_duration": (achieved_launch / HBM_PEAK_GBS) if achieved_launch else None,
-                         "algorithmic_bytes_per_frame": bytes_per_frame,
-                         "whole_step_frac": frames_per_step * bytes_per_frame / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_frame": bytes_per_frame,
+                         "kernel": kname,
+                         "what": "achieved = algorithmic bytes of a K1 launch / mean K1 launch duration in the kernel leg: "
+                                 f"{nk} stream-ordered steps with ONE batch in flight inside this run, K1 bracketed by HIP "
+                                 "events on its launch stream -- no launch overlaps another, so this is the figure "
+                                 "`rocprofv3 --kernel-trace --stats -- python bench.py --inflight 1` reports",
+                         "kernel_ms": kernel_ms, "kernel_ms_stats": _stats(k1_alone), "kernel_ms_samples": int(nk),
+                         "kernel_leg_ms_per_step": leg_ms,
+                         "whole_step_frac": alg_bytes / (elapsed / total_steps) / 1e9 / HBM_PEAK_GBS,
+                         "in_flight": {"what": "K1 brackets of the reported windows: with several batches in flight the "
+                                               "launches overlap and share the machine (duration > busy time per launch)",
+                                       "launch_ms_stats": _stats(k1_inflight),
+                                       "busy_ms_per_launch": busy_per_launch,
+                                       "launches_running_on_average": (sum(k1_inflight) / busy_ms) if busy_ms > 0 else None,
+                                       "frac_by_busy_time": (alg_bytes / (busy_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                       if busy_per_launch else None}},
             "cpu_baseline": cpu,
             "reference_cpu_baseline": _reference_cpu_record(),
-            "settle": {"settle_ms": args.settle_ms, "untimed_steps_between_windows": settle_steps,
-                       "first_window": {"what": f"the {args.steps} steps right after the {args.warmup} warm-up steps "
-                                                "(power-management transient of the first ~30 ms of load)",
-                                        "ms_per_step": first_elapsed / args.steps * 1e3,
-                                        "value": world * frames_per_step * args.steps / first_elapsed,
-                                        "kernel_ms_stats": _stats(first[2])}},
-            "host_issue_ms_per_step": issue / args.steps * 1e3,
             "confidence_pass_ms": conf_ms,
             "gather_ms": gather_ms,
-            "rank_ms_per_step": rank_ms,
             "ranks": ranks,
         }
         print(json.dumps(line))
@@ -631,14 +669,14 @@ def c4_main(args, rk):
 
 
 def c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed):
-    """Rank 0, after the gather: a stratified sample (every length stratum + the longest utterances) is synthesised
+    """Rank 0, after the gather: a stratified sample (every length stratum + the 32 longest utterances) is synthesised
     again from the global indices, its input checksum compared with the one the owning rank gathered, and the
     gathered records compared with the oracle's."""
     from oracle import oracle as ora
     n_total = len(T)
     n = min(args.parity_sample, n_total)
     order = np.argsort(T, kind="stable")
-    longest = order[-min(16, n):]
+    longest = order[-min(32, n):]
     strat = order[np.linspace(0, n_total - 1, max(0, n - len(longest))).astype(np.int64)]
     sample = np.unique(np.concatenate([longest, strat]))
     prm = ora.make_params(C - 1, 0)
@@ -665,6 +703,162 @@ def c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed):
     return {"utterances": int(len(sample)), "frames": frames, "longest_T": int(T[sample].max()),
             "mismatching_utterances": mism, "regenerated_inputs_differing": bad_inputs,
             "oracle_s": w, "oracle_frames_per_s_1core": frames / w if w > 0 else None}
+
+
+# --------------------------------------------------------------------------------------------- realtext
+def realtext_main(args, rk):
+    """`--config realtext`: what the reference does with a REAL transcript (core.py:897-937): raw logits of both heads
+    (ph66 C = 67, groups C = 17), targets with SIL (punctuation) -> the silence-anchored segmented mode
+    (forced_alignment.py:268-469) in both heads, then coverage + soft boundaries (core.py:925-931) and confidences
+    (core.py:936-937) per head.  One step = bfa_align_heads -> bfa_postprocess x2 -> bfa_confidences x2 on device-resident
+    logits; nothing synchronises inside a step.  Parity: the first `--parity-sample` utterances of the batch through
+    the oracle's whole chain (log_softmax -> decode -> coverage -> soft boundaries -> confidences), both heads."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch, _lib
+    from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+    from bournemouth_forced_aligner_amd.utils import postprocess_batch
+    from tools.synth import synth_realtext
+    dev, rank, world = rk.dev, rk.rank, rk.world
+    B, T, S = args.batch, args.frames, args.tokens
+    K = args.steps
+    nfl = max(1, args.inflight or 1)
+    nbuf = max(2, nfl)
+    bufs = [synth_realtext(B, T, S, 2003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
+    T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
+    S_len = torch.full((B,), S, dtype=torch.int32, device=dev)
+    slots = []
+    for k in range(nfl):
+        ap, ag = AlignmentUtils(blank_id=66, silence_id=0), AlignmentUtils(blank_id=16, silence_id=0)
+        ap.viterbi_decoder.handle_slot = ag.viterbi_decoder.handle_slot = k
+        slots.append((ap, ag))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)] if nfl > 1 else [None]
+    vd = slots[0][0].viterbi_decoder
+    hints = [vd.class_mask_hint([T] * B, [S] * B, has_sil=True, n_classes=67),
+             vd.class_mask_hint([T] * B, [S] * B, has_sil=True, n_classes=17)]
+    soft = 3  # PhonemeTimestampAligner(boundary_softness=3) (core.py:41)
+    counter = [0]
+    last = [None]
+
+    def one(ap, ag, buf):
+        xp, xg, tp, tg = buf
+        (rp, sp), (rg, sg) = align_heads([ap, ag], [xp, xg], [tp, tg], T_len, S_len, class_masks=hints)
+        out = []
+        for x, r, st in ((xp, rp, sp), (xg, rg, sg)):
+            postprocess_batch(x, S_len, r.segs, r.seg_count, extend=True, boundary_softness=soft, row_stats=st)
+            cf, cs = calculate_confidences_batch(x, r.segs, r.seg_count, row_stats=st)
+            out.append((r, cf, cs))
+        return out
+
+    def run_steps(n):
+        for _ in range(n):
+            i = counter[0]
+            counter[0] += 1
+            k = i % nfl
+            if streams[k] is None:
+                last[0] = one(*slots[k], bufs[i % nbuf])
+            else:
+                with torch.cuda.stream(streams[k]):
+                    last[0] = one(*slots[k], bufs[i % nbuf])
+
+    run_steps(max(1, args.warmup))
+    torch.cuda.synchronize()
+    for r, _cf, cs in last[0]:
+        st = r.status.cpu().numpy()
+        assert (st == 0).all() and int((cs.cpu() != 0).sum()) == 0, f"alignment failed on the realtext workload: {np.unique(st)}"
+    first_t, _ = _timed_windows(rk, run_steps, K, 1)
+    settle_steps = 0
+    if args.settle_ms > 0:
+        s0 = time.perf_counter()
+        while (time.perf_counter() - s0) * 1e3 < args.settle_ms:
+            run_steps(4)
+            settle_steps += 4
+            torch.cuda.synchronize()
+    warm_eff = counter[0]
+    n_windows = max(1, -(-args.min_timed_steps // K))
+    win_t, issue_t = _timed_windows(rk, run_steps, K, n_windows)
+    total_steps = K * n_windows
+    elapsed = float(np.sum(win_t))
+    win_ms = [t / K * 1e3 for t in win_t]
+    modes = [r.mode.cpu().numpy() for r, _cf, _cs in last[0]]
+
+    # algorithmic bytes per frame (SURVEY.md 8(d) + the "-sil" prepass): each head's matrix read once by K1, the
+    # phoneme head's once more by the P(SIL) prepass K0, 2-bit backpointers and the two framewise outputs per head
+    L = 4 * S + 1
+    bpf = 4 * 67 + 4 * 17 + 4 * 67 + 2 * ((L + 3) // 4) + 2 * 8
+    frames = B * T
+    step_s = elapsed / total_steps
+    # ---- parity: one more step on buffer 0, the first n utterances against the oracle's whole chain
+    parity = None
+    if rank == 0 and args.parity_sample > 0:
+        parity = realtext_parity(args, slots[0], one, bufs[0], T, S, soft)
+    ranks = rk.describe()
+    if rank == 0:
+        line = {
+            "metric": "aligned frames/sec (whole node) on ph66 posteriors, real-text workload (both heads from raw logits, "
+                      "SIL in the targets)", "value": world * frames / step_s,
+            "unit": "aligned frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"realtext: batch={B} T={T} |tokens|={S}, ph66 head (C=67) + group head (C=17) from RAW "
+                                   f"logits, SIL at ~1/12 of the target positions with planted 12-40-frame silences, "
+                                   f"reference-default flags; step = bfa_align_heads + bfa_postprocess x2 + "
+                                   f"bfa_confidences x2; {nfl} step(s) in flight",
+                       "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+            "timing": {"windows": n_windows, "timed_steps_total": total_steps,
+                       "window_ms_per_step": {"mean": float(np.mean(win_ms)), "min": float(np.min(win_ms)),
+                                              "max": float(np.max(win_ms)), "all": win_ms},
+                       "warmup_requested_steps": args.warmup, "warmup_effective_steps": warm_eff,
+                       "first_window_ms_per_step": first_t[0] / K * 1e3,
+                       "host_issue_ms_per_step": float(np.sum(issue_t)) / total_steps * 1e3},
+            "roofline": {"bound": "hbm", "achieved": frames * bpf / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": frames * bpf / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole step (K0 row pass + planner + piece DPs + walks of both heads, post-DP stages)",
+                         "algorithmic_bytes_per_frame": bpf,
+                         "algorithmic_bytes_what": "4*67 (K1, ph66) + 4*17 (K1, groups) + 4*67 (K0 prepass, ph66) + "
+                                                   "2*ceil(L/4) backpointers + 2*8 framewise outputs"},
+            "segmented_utterances": {"ph66": int((modes[0] == 1).sum()), "groups": int((modes[1] == 1).sum()), "of": B},
+            "parity": parity,
+            "ranks": ranks,
+        }
+        print(json.dumps(line))
+
+
+def realtext_parity(args, slot, one, buf, T, S, soft):
+    from oracle import oracle as ora
+    n = min(args.parity_sample, buf[0].shape[0])
+    got = one(*slot, buf)
+    torch.cuda.synchronize()
+    mism = {"ph66": 0, "groups": 0}
+    conf_bad = {"ph66": 0, "groups": 0}
+    max_conf_diff = 0.0
+    tuples = 0
+    w0 = time.perf_counter()
+    for hi, (name, blank) in enumerate((("ph66", 66), ("groups", 16))):
+        x = buf[hi][:n].cpu().numpy()
+        tk = buf[2 + hi][:n].cpu().numpy()
+        r, cf, _cs = got[hi]
+        gs, gc, gcf = r.segs[:n].cpu().numpy(), r.seg_count[:n].cpu().numpy(), cf[:n].cpu().numpy()
+        prm = ora.make_params(blank, 0)
+        for b in range(n):
+            lp = ora.log_softmax_rows(x[b])
+            res = ora.decode_alignments(lp[None], tk[b][None], [T], [S], prm)
+            rows = ora.segments_as_lists(res)[0]
+            cov = ora.ensure_target_coverage_default(rows, S)
+            ext = ora.extend_soft_boundaries(lp, cov, soft) if cov else []
+            mine = [tuple(int(v) for v in row) for row in gs[b, :gc[b]]]
+            if mine != [tuple(int(v) for v in e[:4]) for e in ext]:
+                mism[name] += 1
+                continue
+            rc, c, _s, _e = ora.confidences(lp, ext)
+            tuples += len(ext)
+            d = float(np.abs(gcf[b, :len(ext)] - c).max()) if len(ext) else 0.0
+            max_conf_diff = max(max_conf_diff, d)
+            if rc != 0 or d > 1e-4:
+                conf_bad[name] += 1
+    return {"utterances": n, "heads": 2, "tuples_compared": tuples, "mismatching_utterances": mism,
+            "confidence_beyond_1e-4": conf_bad, "max_confidence_abs_diff": max_conf_diff,
+            "oracle_s": time.perf_counter() - w0,
+            "what": "rows after coverage + soft boundaries bit-exact, confidences within 1e-4, vs oracle/ (log_softmax -> "
+                    "decode_alignments -> ensure_target_coverage -> extend_soft_boundaries -> confidences)"}
 
 
 # ----------------------------------------------------------------------------------------------- ragged
@@ -722,10 +916,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["headline", "c4"], default="headline")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="headline, experiment (measured: slower than plain calls): n decoders taking turns on one stream "
-                         "with a shared tail stream (bfa_set_tail_stream); 1 = off")
+    ap.add_argument("--config", choices=["headline", "c2", "c4", "realtext"], default="headline",
+                    help="headline = BASELINE configs[2]; c2 = configs[1] (batch 256, T 600, 20 tokens) through the headline "
+                         "path; c4 = configs[3]; realtext = both heads from raw logits with SIL in the targets")
+    ap.add_argument("--min-timed-steps", type=int, default=100,
+                    help="the reported figure covers ceil(this / --steps) windows of exactly --steps steps (SURVEY 8(d): >= 100)")
+    ap.add_argument("--kernel-leg-steps", type=int, default=40,
+                    help="headline: steps of the one-batch-in-flight leg that prices the kernel for `roofline`")
+    ap.add_argument("--row-pitch", type=int, default=0,
+                    help="headline A/B: posterior rows padded to this many floats (e.g. 72 = 288-byte rows), 0 = dense")
     ap.add_argument("--tlo", type=int, default=200, help="--ragged: shortest utterance")
     ap.add_argument("--thi", type=int, default=3000, help="--ragged: longest utterance")
     ap.add_argument("--batch", type=int, default=4096)
@@ -748,7 +947,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=32768, help="c4: utterances over all ranks")
     ap.add_argument("--chunk", type=int, default=16384, help="c4: utterances per bfa_align_batch call (one call per rank when the shard is smaller)")
     ap.add_argument("--seed", type=int, default=1004, help="c4: generator seed")
-    ap.add_argument("--parity-sample", type=int, default=256, help="c4: utterances rank 0 checks against the oracle")
+    ap.add_argument("--parity-sample", type=int, default=None,
+                    help="utterances rank 0 checks against the oracle (c4: default 256, stratified; realtext: default 512)")
     ap.add_argument("--dry-run", action="store_true", help="launch + partition + gather plumbing on gloo, no GPU work")
     ap.add_argument("--force-group", action="store_true",
                     help="initialise the process group even at world size 1 (exercises the N > 1 code path of the headline mode)")
@@ -757,11 +957,17 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
 
+    if args.config == "c2":
+        args.batch, args.frames, args.tokens = 256, 600, 20
+    if args.parity_sample is None:
+        args.parity_sample = 512 if args.config == "realtext" else 256
     rk = Ranks(args, need_group=(args.config == "c4" or args.force_group))
     if args.ragged:
         ragged_main(args, rk)
     elif args.config == "c4":
         c4_main(args, rk)
+    elif args.config == "realtext" and not args.dry_run:
+        realtext_main(args, rk)
     elif args.dry_run:
         dry_headline(args, rk)
     else:

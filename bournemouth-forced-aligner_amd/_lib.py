@@ -18,14 +18,14 @@ MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
            "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
            "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
-           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_set_tail_stream",
-           "bfa_profile_collect_spans"]
+           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_profile_collect_spans"]
 
 
 class BfaParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "blank_id", "silence_id", "silence_anchors", "ignore_noise", "truly_forced", "boost_targets",
-        "enforce_minimum", "simple", "max_blanks", "class_mask", "window_max_tokens", "window_max_frames")]
+        "enforce_minimum", "simple", "max_blanks", "class_mask", "window_max_tokens", "window_max_frames",
+        "has_min_log_prob")] + [("min_log_prob", ctypes.c_float)]
 
 
 class BfaHead(ctypes.Structure):
@@ -85,7 +85,6 @@ def lib():
     L.bfa_align_heads.argtypes = [vp, ctypes.POINTER(BfaHead), i32, i32, i32, vp, vp, vp]
     L.bfa_log_softmax.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
     L.bfa_stitch_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i64, i64, vp]
-    L.bfa_set_tail_stream.argtypes = [vp, vp]
     L.bfa_profile_enable.argtypes = [vp, i32]
     L.bfa_profile_collect_spans.argtypes = [vp, vp, vp, vp, i32]
     L.bfa_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32]

@@ -15,8 +15,12 @@ import numpy as np
 import torch
 
 from .coverage import ensure_target_coverage
-from .forced_alignment import AlignmentUtils, align_heads
+from .forced_alignment import AlignmentUtils, align_heads, rows_as_tuple_lists
 from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
+
+# one row of extract_timestamps_from_segment_batch's result (core.py:939-956)
+_ROW8 = np.dtype([("id", "<i4"), ("start", "<i4"), ("end", "<i4"), ("idx", "<i4"), ("est", "?"), ("conf", "<f4"),
+                  ("start_ms", "<f4"), ("end_ms", "<f4")])
 
 
 def _pad_rows(rows, fill):
@@ -112,36 +116,36 @@ class PhonemeTimestampAligner:
         fn = getattr(self.phonemizer, "phonemize_sentence", None) or self.phonemizer
         return fn(text)
 
-    @staticmethod
-    def _rms_normalize(audio):
-        """core.py:314-320"""
-        rms = torch.sqrt(torch.mean(audio ** 2))
-        if rms > 0:
-            audio = audio / rms
-        return audio
-
     @torch.no_grad()
-    def chop_wav(self, wav, start_frame, end_frame):
-        """core.py:276-311: slice [C, start:end], channel mean, RMS normalise, pad / truncate to wav_len_max.
-        Returns (wav, wav_len, error_code)."""
-        num_frames = (end_frame - start_frame) if (end_frame != -1) else -1
-        if num_frames < self.seg_duration_min_samples:
-            print(f"ERROR: Segment too short: {num_frames} frames, minimum required is {self.seg_duration_min_samples} frames.")
-            return None, None, -1
-        wav = wav[:, start_frame:end_frame]
-        assert (wav.shape[1] <= num_frames) or (num_frames == -1)
-        if wav.shape[1] < self.seg_duration_min_samples:
-            print(f"Wav shape is too small: {wav.shape}, start_frame: {start_frame}, end_frame: {end_frame}")
-            return None, None, -2
-        wav = wav.mean(dim=0)
-        wav = self._rms_normalize(wav)
-        wav_len = wav.shape[0]
-        if wav_len > self.wav_len_max:
-            wav = wav[:self.wav_len_max]
-            wav_len = wav.shape[0]
-        else:
-            wav = torch.nn.functional.pad(wav, (0, self.wav_len_max - wav.shape[0]), "constant", 0)
-        return wav, wav_len, 0
+    def _chop_segments(self, clips, spans):
+        """The audio front end of process_segments for ALL sub-segments at once (what core.py:276-320 does one segment
+        at a time): segment i is samples [lo_i, hi_i) of clip i (a (channels, samples) tensor), down-mixed to mono,
+        scaled to unit RMS over the whole segment, and laid into row i of one zero-filled [N, wav_len_max] matrix
+        (longer segments are cut).  Returns (matrix, lengths, codes): code -1 = the requested span is shorter than
+        `seg_duration_min_samples` (an end of -1 counts as that), -2 = the clip ends before the span is long enough;
+        rows with a non-zero code stay zero and have length 0."""
+        n = len(spans)
+        codes = [0] * n
+        lengths = [0] * n
+        first = clips[0]
+        out = torch.zeros((n, self.wav_len_max), dtype=first.dtype if first.is_floating_point() else torch.float32,
+                          device=first.device)
+        for i, (clip, (lo, hi)) in enumerate(zip(clips, spans)):
+            if hi == -1 or hi - lo < self.seg_duration_min_samples:
+                codes[i] = -1
+                continue
+            piece = clip[:, lo:hi]
+            if piece.shape[1] < self.seg_duration_min_samples:
+                codes[i] = -2
+                continue
+            mono = piece.mean(dim=0)
+            level = mono.square().mean().sqrt()
+            if level > 0:
+                mono = mono / level
+            k = min(mono.shape[0], self.wav_len_max)
+            out[i, :k] = mono[:k]
+            lengths[i] = k
+        return out, lengths, codes
 
     def _setup_decoders(self):
         """core.py:252-257"""
@@ -285,8 +289,16 @@ class PhonemeTimestampAligner:
         if as_arrays:
             return {"rows": segs, "count": cnt, "is_estimated": est, "confidence": cf[:, :cap], "start_ms": sms,
                     "end_ms": ems}
-        cols = [segs[:, :, k].tolist() for k in range(4)] + [est.tolist(), cf[:, :cap].tolist(), sms.tolist(), ems.tolist()]
-        return [list(zip(*(c[b][:int(cnt[b])] for c in cols))) for b in range(B)]
+        # the reference's 8-tuples: the valid rows of the whole batch as ONE structured array, turned into tuples by
+        # numpy in one pass and cut per utterance -- not B x 8 slices and B zips
+        ncl = np.minimum(cnt, cap)
+        valid = np.arange(cap)[None, :] < ncl[:, None]
+        rec = np.empty(int(ncl.sum()), dtype=_ROW8)
+        picked = segs[valid]
+        for k, name in enumerate(("id", "start", "end", "idx")):
+            rec[name] = picked[:, k]
+        rec["est"], rec["conf"], rec["start_ms"], rec["end_ms"] = est[valid], cf[:, :cap][valid], sms[valid], ems[valid]
+        return rows_as_tuple_lists(rec, ncl)
 
     def extract_timestamps_from_segment_batch(self, wavs, wav_lens, phoneme_sequences, start_offset_times=0,
                                               group_sequences=None, extract_embeddings=False, do_groups=True,
@@ -493,7 +505,7 @@ class PhonemeTimestampAligner:
                          debug=False):
         """core.py:1212-1487, step for step: normalise the inputs (a dict -> a one-clip batch; a (C,T) / (B,C,T) tensor
         -> list of (C,T) clips), flatten the sub-segments of all clips, phonemise, drop sequences shorter than
-        `ph_seq_min`, chop + RMS-normalise + pad the audio (`chop_wav`), run the extraction in one call -- or, when
+        `ph_seq_min`, cut / down-mix / RMS-normalise / pad the audio of all segments (`_chop_segments`), run the extraction in one call -- or, when
         `batch_size < number of segments`, in slices whose `ValueError` ("Audio too short to align", core.py:1367-1386)
         turns that slice into empty results; in the one-call branch the error propagates like in the reference --
         post-process, regroup per clip, then the confidence analysis that can set `coverage_analysis.bad_alignment`.
@@ -545,9 +557,9 @@ class PhonemeTimestampAligner:
         grp_f = [group_sequences[i] for i in valid]
         ts_f = [ts_outs[i] for i in valid]
 
-        chopped = [self.chop_wav(clip_wav, int(seg["start"] * self.resampler_sample_rate),
-                                 int(seg["end"] * self.resampler_sample_rate)) for _, seg, clip_wav in flat_f]
-        wavs, wav_lens, codes = zip(*chopped)
+        rate = self.resampler_sample_rate
+        wavs, wav_lens, codes = self._chop_segments([clip_wav for _, _, clip_wav in flat_f],
+                                                    [(int(seg["start"] * rate), int(seg["end"] * rate)) for _, seg, _ in flat_f])
         keep = [i for i, code in enumerate(codes) if code == 0]
         if len(keep) < len(flat_f):
             if debug or self.warn_level >= 1:
@@ -559,12 +571,10 @@ class PhonemeTimestampAligner:
             ph_f = [ph_f[i] for i in keep]
             grp_f = [grp_f[i] for i in keep]
             ts_f = [ts_f[i] for i in keep]
-            wavs = [wavs[i] for i in keep]
+            wavs = wavs[keep]
             wav_lens = [wav_lens[i] for i in keep]
-        if not wavs:
+        if not keep:
             raise ValueError("All segments have audio chopping errors. Cannot proceed with timestamp extraction.")
-        wavs = torch.stack(list(wavs), dim=0)
-        wav_lens = list(wav_lens)
         start_times = [seg["start"] for _, seg, _ in flat_f]
 
         if batch_size < len(flat_items):  # (the reference compares with the UNfiltered count)

@@ -263,6 +263,7 @@ __device__ __forceinline__ void walk_item(const AlignArgs &a, const Item &it, ui
                 if (run > 0) {
                     if (lane <= hi_l && lane > hi_l - run) my_state = sp;
                     s -= 2 * run;
+                    if (s < 0) s += L; // the run's last move may leave state 0 / 1 downwards: python negative-index wrap (:692)
                     sl = s / R; sr = s - sl * R;
                     t_hi -= run;
                 }
@@ -423,6 +424,7 @@ __device__ __forceinline__ void walk_item_mask(const AlignArgs &a, const Item &i
                     if (run > 0) {
                         if (lane <= hi && lane > hi - run) my_state = sp;
                         s -= 2 * run;
+                        if (s < 0) s += L; // (the run's last move may leave state 0 / 1 downwards: the wrap of :692)
                         hi -= run;
                         todo &= (hi >= 0) ? ((2ull << hi) - 1ull) : 0ull;
                     }

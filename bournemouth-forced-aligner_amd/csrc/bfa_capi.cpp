@@ -15,8 +15,7 @@
 #include "bfa_types.hpp"
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void *fork_event, int naux, void *tail_stream,
-                                void *tail_fork_event);
+                                void **aux_streams, void **aux_events, void *fork_event, int naux);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
@@ -44,17 +43,7 @@ struct bfa_context {
     // bfa_align_heads: heads after the first are enqueued on this stream (forked from / joined into the caller's)
     hipStream_t head_stream = nullptr;
     hipEvent_t head_fork = nullptr, head_join = nullptr;
-    // bfa_set_tail_stream: the part of a call behind K1 (rerun launch, walk, run-length encoding) goes to this stream
-    hipStream_t tail = nullptr;
-    hipEvent_t tail_fork = nullptr, tail_done = nullptr;
-    bool tail_pending = false; // a call's tail has been enqueued and nothing has been ordered behind it yet
 };
-
-// a later call on this handle (same workspace, same outputs) or a reader of its outputs: behind the pending tail
-static void order_behind_tail(bfa_context *h, void *stream)
-{
-    if (h->tail_pending && h->tail_done) (void)hipStreamWaitEvent((hipStream_t)stream, h->tail_done, 0);
-}
 
 namespace {
 
@@ -268,8 +257,6 @@ int bfa_destroy(bfa_handle h)
         if (h->head_stream) (void)hipStreamDestroy(h->head_stream);
         if (h->head_fork) (void)hipEventDestroy(h->head_fork);
         if (h->head_join) (void)hipEventDestroy(h->head_join);
-        if (h->tail_fork) (void)hipEventDestroy(h->tail_fork);
-        if (h->tail_done) (void)hipEventDestroy(h->tail_done);
     }
     delete h;
     return BFA_OK;
@@ -291,7 +278,7 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
                     const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
                     const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
                     bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
-                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream, bool allow_tail = false)
+                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(h);
@@ -336,6 +323,8 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
     a.p.class_mask = (uint32_t)params->class_mask; a.p.win_mask = 0;
     a.p.win_max_tokens = params->window_max_tokens > 0 ? params->window_max_tokens : bfa::WIN_MAX_TOKENS;
     a.p.win_max_frames = params->window_max_frames > 0 ? params->window_max_frames : bfa::WIN_MAX_FRAMES;
+    a.p.min_logp = params->has_min_log_prob ? params->min_log_prob : bfa::MIN_LOGP;
+    if (a.p.min_logp != a.p.min_logp) return fail(h, BFA_ERR_INVALID_ARGUMENT, "min_log_prob is NaN");
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
     // one wavefront per work item; surplus items are taken by the blocks' stride loops
@@ -348,13 +337,9 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
         h->events.push_back(pr);
         ev0 = (void *)pr.first; ev1 = (void *)pr.second;
     }
-    const bool use_tail = allow_tail && h->tail && h->tail_fork && h->tail_done;
-    order_behind_tail(h, stream); // (the previous call of this handle may still be walking in the same workspace)
     const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done, (void *)h->forked,
-                                    h->forked ? h->naux : 0, use_tail ? (void *)h->tail : nullptr, (void *)h->tail_fork);
+                                    h->forked ? h->naux : 0);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
-    if (use_tail) { (void)hipEventRecord(h->tail_done, h->tail); h->tail_pending = true; }
-    else h->tail_pending = false;
     return BFA_OK;
 }
 
@@ -369,20 +354,7 @@ int bfa_align_batch(bfa_handle h, const float *logp, int64_t strideB, int64_t st
 {
     return align_impl(h, logp, nullptr, strideB, strideT, B, Tmax, C, T_len, tokens, S_len, Smax, params,
                       out_frame_phoneme, out_frame_idx, out_segs, seg_cap, out_seg_count, out_status, out_mode, workspace,
-                      workspace_bytes, stream, /*allow_tail=*/true);
-}
-
-int bfa_set_tail_stream(bfa_handle h, void *tail_stream)
-{
-    if (!h) return BFA_ERR_INVALID_ARGUMENT;
-    DeviceGuard guard(h);
-    if (tail_stream && !h->tail_fork) {
-        if (hipEventCreateWithFlags(&h->tail_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->tail_done, hipEventDisableTiming) != hipSuccess)
-            return fail(h, BFA_ERR_LAUNCH, "bfa_set_tail_stream: cannot create events");
-    }
-    h->tail = (hipStream_t)tail_stream;
-    return BFA_OK;
+                      workspace_bytes, stream);
 }
 
 int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int Tmax, const int32_t *T_len,
@@ -394,7 +366,6 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
     for (int k = 0; k < n_heads; ++k)
         if (!heads[k].logits || !heads[k].out_row_stats) return fail(h, BFA_ERR_INVALID_ARGUMENT, "head without logits / out_row_stats");
     const bool side = n_heads > 1 && h->head_stream != nullptr;
-    order_behind_tail(h, stream);
     if (side) {
         (void)hipEventRecord(h->head_fork, (hipStream_t)stream);
         (void)hipStreamWaitEvent(h->head_stream, h->head_fork, 0);
@@ -440,6 +411,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
     a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = 0;
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = 1; a.p.max_blanks = 10;
     a.p.class_mask = 0; a.p.win_mask = 0; a.p.win_max_tokens = 0; a.p.win_max_frames = 0;
+    a.p.min_logp = params->has_min_log_prob ? params->min_log_prob : bfa::MIN_LOGP;
     // k_plan also writes seg_count/status: point them at scratch
     a.seg_count = a.uS; a.status = a.umode; a.seg_cap = 1;
     a.seg_count = (int32_t *)a.frame_ph; a.status = (int32_t *)a.frame_idx;
@@ -456,7 +428,6 @@ int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t s
     DeviceGuard guard(h);
     if (!logp || !segs || !seg_count || !out_conf) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
-    order_behind_tail(h, stream); // (the tuples may come from a call whose tail is still running on the tail stream)
     bfa::ConfArgs a;
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.T_rows = T_rows;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.conf = out_conf; a.status = out_item_status;
@@ -474,7 +445,6 @@ int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t s
     if (!logp || !S_len || !segs || !seg_count) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
     if (seg_cap > 6500) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 6500 in bfa_postprocess (24 bytes of LDS per tuple)");
-    order_behind_tail(h, stream);
     // core.py:699-701 : python `10.0 ** -n` is libm pow on doubles
     const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)boundary_softness);
     const int rc = bfa_launch_postprocess(logp, row_stats, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, extend,

@@ -313,8 +313,7 @@ extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, in
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void *fork_event, int naux, void *tail_stream,
-                                void *tail_fork_event)
+                                void **aux_streams, void **aux_events, void *fork_event, int naux)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
@@ -336,6 +335,8 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
             if (top > 0 && rw > top) wmask &= ~(1u << (rw - 1));
         if (p.class_mask) wmask &= (p.class_mask >> 8);
     }
+    // (the window result is exact because emissions are <= 0; a floor above log(1) = 0 would break that argument)
+    if (!(p.min_logp <= 0.0f)) wmask = 0;
     a.p.win_mask = wmask;
     mask |= wmask << 8;
     // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
@@ -376,15 +377,6 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, &fan);
     fan.join();
-    // bfa_set_tail_stream: everything behind K1 (rerun launch, walk, run-length encoding: ~15 % of a headline step, latency
-    // chains that leave the machine mostly idle) goes to the tail stream, so that the caller's stream is free for the K1
-    // of the next call (another handle, another workspace) at once
-    if (tail_stream) {
-        if (ev1) { (void)hipEventRecord((hipEvent_t)ev1, stream); ev1 = nullptr; } // (the K1 bracket ends here)
-        (void)hipEventRecord((hipEvent_t)tail_fork_event, stream);
-        stream = (hipStream_t)tail_stream;
-        (void)hipStreamWaitEvent(stream, (hipEvent_t)tail_fork_event, 0);
-    }
     const bool redo_done = a.k2_windows && (a.C == 67 || a.C == 17); // (launched behind the window kernels on their stream, bfa_dp3.inc)
     if (redo_done) { /* nothing */ }
     else if (nk <= 2) bfa_launch_dp_redo_nk2(&a, mask, mode, stream);
@@ -396,7 +388,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const bool any_wide = (mask & (0x78u | (0xa0u << 8))) != 0 || Lmax > 256;
     if (per_class_k2) {
         // window / rerun items, fills, items nobody took: wide only if a window item (or its full-layout rerun) can be
-        const bool rest_wide = (mask & (0xa0u << 8)) != 0 || (wmask != 0 && Lmax > 256);
+        const bool rest_wide = (mask & (0xa0u << 8)) != 0 || Lmax > 256; // (also wide items whose K1 class the hint left out: they are reported as BAD_HINT by the wide walk)
         bfa_launch_backtrace_sel(&a, a.k2_windows ? K2_REST_NOWIN : K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
         if (!fused_k2) hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     } else {

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void k_silprob(AlignArgs a)
 #pragma unroll
             for (int k = 0; k < NK; ++k) x[k] = lp[(int64_t)row * a.strideT + min(16 * k + j, a.C - 1)];
             if (a.row_stats) softmax16<NK>(x, rl.valid); // raw logits in
-            boost_floor<NK>(x, rl, p.boost != 0, p.enforce != 0);
+            boost_floor<NK>(x, rl, p.boost != 0, p.enforce != 0, p.min_logp);
             float v = 0.0f;
 #pragma unroll
             for (int k = 0; k < NK; ++k) if (k == sil_k) v = x[k];
@@ -181,13 +181,17 @@ struct PlanScratch {
     SegRec *segs;
     int aud_cap;
     float *cs; // LDS, cooperative mode only
+    int32_t *gsub; // cooperative mode: the utterance's global sub-silence scratch, for a piece whose runs overflow the LDS array
+    int gsub_cap;
 };
 
 // COOP: executed by every lane of the wavefront with identical control flow (all decisions depend on wave-uniform
 // data); scratch lives in LDS, the heavy loops are lane-parallel and global side effects come from lane 0.
 // !COOP: executed by lane 0 alone (utterances too large for the LDS arrays).
+// Returns false (cooperative mode only, nothing written yet) when the audio silences do not fit the LDS array: the
+// caller then plans the utterance with the global scratch, which holds the true worst case.
 template <bool COOP>
-__device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const PlanScratch &sc, int lane)
+__device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const PlanScratch &sc, int lane)
 {
     const bool writer = !COOP || lane == 0;
     auto silences = [&](const float *x, int Tx, float thr, int k, int32_t *out, int cap) {
@@ -240,9 +244,14 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
         }
         if (na == 0 && S > 200 && mf > 3) { mf = 3; na = silences(ps, T, 0.9f, mf, aud, aud_cap); }
         // More silence runs than the scratch holds (runs only need one silent window followed by a non-silent one, so
-        // there can be about nwin / 2 of them -- P(SIL) oscillating around the threshold at every frame): reported as
-        // BFA_ITEM_TOO_LARGE, never as a silently different (standard-mode) alignment.
-        if (na < 0) { if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; } return; }
+        // there can be about nwin / 2 of them -- P(SIL) oscillating around the threshold at every frame).  LDS scratch:
+        // the caller repeats the plan with the global scratch (sized for that worst case).  Global scratch (cannot
+        // happen with the documented workspace size): BFA_ITEM_TOO_LARGE, never a silently different alignment.
+        if (na < 0) {
+            if (COOP) return false;
+            if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; }
+            return true;
+        }
         if (na <= 0) ok = false; // :315-320
     }
     // ---- _match_silences :226-266
@@ -324,9 +333,9 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
             if (fallback_mode == BFA_FALLBACK_TOO_SHORT) { a.status[b] = BFA_ITEM_TOO_SHORT; a.umode[b] = BFA_MODE_EMPTY; }
             else a.umode[b] = fallback_mode;
         }
-        return;
+        return true;
     }
-    if (too_large) { if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; } return; }
+    if (too_large) { if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; } return true; }
     // pieces are CONCATENATED (:453-467): audio silences may overlap, so a piece's output position is the
     // running length, not its audio position; the result is truncated / blank-padded to T frames
     npieces += 1; // room for the blank tail
@@ -334,7 +343,7 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
     if (COOP) base = __builtin_amdgcn_readfirstlane(base);
     if (base + npieces > a.item_cap) { // cannot happen with the documented workspace size
         if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; }
-        return;
+        return true;
     }
     // ---- emit one item per piece (:377-451)
     int64_t bp_off = (int64_t)b * a.bp_per_utt;
@@ -365,21 +374,31 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
             bp_off += bp_dwords(Ts, L);
             // sub-silences of the padded slice get +5 on blank and a re-normalisation, once per
             // (possibly overlapping) detected segment (:415-419, :543-561)
-            const int nsub = silences(ps + psx, Ts, 0.8f, mf, sub, aud_cap);
-            // scratch or anchor pool exhausted (pathological inputs, see above): flag the utterance instead of skipping
+            int nsub = silences(ps + psx, Ts, 0.8f, mf, sub, aud_cap);
+            const int32_t *subr = sub;
+            if (COOP && nsub < 0) { // more runs than the LDS array holds: lane 0 detects them again into the global scratch
+                int n2 = 0;
+                if (lane == 0) n2 = detect_silence(ps + psx, Ts, 0.8f, mf, sc.gsub, sc.gsub_cap);
+                nsub = __builtin_amdgcn_readfirstlane(n2);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                subr = sc.gsub;
+            }
+            // scratch or anchor pool exhausted (cannot happen with the documented workspace size): flag the utterance
             if ((nsub < 0 || (nsub > 0 && anch_used + Ts > a.anchor_per_utt)) && writer) a.status[b] = BFA_ITEM_TOO_LARGE;
             if (nsub > 0 && anch_used + Ts <= a.anchor_per_utt) {
                 uint8_t *ac = apool + anch_used;
                 if (COOP) { // one frame per lane: how many detected segments cover it
                     for (int f = lane; f < Ts; f += 64) {
                         int cnt = 0;
-                        for (int q = 0; q < nsub; ++q) cnt += (f >= sub[2 * q] && f < sub[2 * q + 1]) ? 1 : 0;
+                        for (int q = 0; q < nsub; ++q) cnt += (f >= subr[2 * q] && f < subr[2 * q + 1]) ? 1 : 0;
                         ac[f] = (uint8_t)cnt;
                     }
                 } else {
                     for (int f = 0; f < Ts; ++f) ac[f] = 0;
                     for (int q = 0; q < nsub; ++q)
-                        for (int f = sub[2 * q]; f < sub[2 * q + 1]; ++f) ac[f] = (uint8_t)(ac[f] + 1);
+                        for (int f = subr[2 * q]; f < subr[2 * q + 1]; ++f) ac[f] = (uint8_t)(ac[f] + 1);
                 }
                 it.anch_off = anch_used;
                 anch_used += Ts;
@@ -402,6 +421,7 @@ __device__ void plan_candidate(const AlignArgs &a, int b, const float *ps, const
         a.items[b].kind = ITEM_NONE; // the standard-mode fallback item is not needed
         a.umode[b] = BFA_MODE_SEGMENTED;
     }
+    return true;
 }
 
 // one wavefront per candidate, planning with LDS scratch (the planner walks its run / group / segment arrays several
@@ -433,22 +453,26 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames)
         const bool coop = T <= lds_frames && (T / min_k + 2 <= PLAN_LDS_SILS) && ((S + 1) / 2 + 1 <= PLAN_LDS_GROUPS);
         __builtin_amdgcn_wave_barrier(); // the previous candidate's readers are done
         PlanScratch sc;
+        bool planned = false;
+        int32_t *const gscr = a.seg_scratch + (int64_t)b * a.seg_scratch_per_utt; // [groups | aud | sub | match | segs]
         if (coop) { // wave-uniform
             // P(SIL) itself stays in global memory: every pass over it is a 64-wide coalesced read one slice ahead of
             // the serial sum, and without a second staged vector all 16 planners of a CU's share of a 4096-utterance
             // batch are resident at once (LDS was the limit: 12 KB each at T = 1000, 2.5 rounds of ~70 us)
             sc.groups = s_groups; sc.aud = s_aud; sc.sub = s_sub; sc.match = s_match; sc.segs = s_segs;
             sc.aud_cap = PLAN_LDS_SILS; sc.cs = scs;
-            plan_candidate<true>(a, b, ps, sc, lane);
-        } else if (lane == 0) {
-            int32_t *scr = a.seg_scratch + (int64_t)b * a.seg_scratch_per_utt;
+            sc.gsub = gscr + 2 * (a.Smax + 2) + 2 * (a.Tmax + 2); sc.gsub_cap = a.Tmax + 2;
+            planned = plan_candidate<true>(a, b, ps, sc, lane);
+        }
+        if (!planned && lane == 0) { // too large for the LDS arrays (by the admission test, or found out while planning)
+            int32_t *scr = gscr;
             sc.groups = scr; scr += 2 * (a.Smax + 2);
             sc.aud = scr; scr += 2 * (a.Tmax + 2);
             sc.sub = scr; scr += 2 * (a.Tmax + 2);
             sc.match = scr; scr += 2 * (a.Smax + 2);
             sc.segs = (SegRec *)scr;
-            sc.aud_cap = a.Tmax + 2; sc.cs = nullptr;
-            plan_candidate<false>(a, b, ps, sc, lane);
+            sc.aud_cap = a.Tmax + 2; sc.cs = nullptr; sc.gsub = nullptr; sc.gsub_cap = 0;
+            (void)plan_candidate<false>(a, b, ps, sc, lane);
         }
     }
 }

@@ -72,9 +72,9 @@ __device__ __forceinline__ void anchor_rows(float (&x)[NK], const RowLane &rl, i
     }
 }
 
-// forced_alignment.py:29-83: +5 on target columns, log_softmax, floor target columns at log(1e-8)
+// forced_alignment.py:29-83: +5 on target columns, log_softmax, floor target columns at log(min_phoneme_prob)
 template <int NK>
-__device__ __forceinline__ void boost_floor(float (&x)[NK], const RowLane &rl, bool boost, bool enforce)
+__device__ __forceinline__ void boost_floor(float (&x)[NK], const RowLane &rl, bool boost, bool enforce, float min_logp)
 {
     if (boost) {
 #pragma unroll
@@ -83,7 +83,7 @@ __device__ __forceinline__ void boost_floor(float (&x)[NK], const RowLane &rl, b
     }
     if (enforce) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) x[k] = ((rl.tmask & (1u << k)) && x[k] < MIN_LOGP) ? MIN_LOGP : x[k];
+        for (int k = 0; k < NK; ++k) x[k] = ((rl.tmask & (1u << k)) && x[k] < min_logp) ? min_logp : x[k]; // :79-81
     }
 }
 

@@ -7,7 +7,7 @@
 namespace bfa {
 
 constexpr float NEG = -1000.0f;                   // forced_alignment.py:23 `_neg_inf` (finite on purpose)
-constexpr float MIN_LOGP = -18.420680999755859375f; // float32 log(1e-8), forced_alignment.py:70
+constexpr float MIN_LOGP = -18.420680999755859375f; // float32 log(1e-8), forced_alignment.py:70 (the default of bfa_params.min_log_prob)
 constexpr int MAX_C = 128;                        // target-column mask is 4 x u32
 constexpr int MASK_WORDS = MAX_C / 32;
 constexpr int MAX_R = 16;                         // CTC states per lane in the wave kernel -> L <= 1024
@@ -54,6 +54,7 @@ struct DevParams {
     uint32_t win_mask;   // sliding-window classes the planner may use (bit Rw-1), set by bfa_launch_align
     int32_t win_max_tokens; // no window attempt for utterances with more tokens
     int32_t win_max_frames; // ... or more frames
+    float min_logp;         // floor of the target columns: float32 log(min_phoneme_prob), forced_alignment.py:70
 };
 
 // everything the kernels of one bfa_align_batch call need; passed by value

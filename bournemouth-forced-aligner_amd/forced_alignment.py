@@ -60,6 +60,30 @@ class _Workspace:
         return self.buf
 
 
+_ROW4 = np.dtype([("phoneme", "<i4"), ("start", "<i4"), ("end", "<i4"), ("target_idx", "<i4")])
+
+
+def rows_as_tuple_lists(records, counts):
+    """`records`: a flat numpy STRUCTURED array, one record per valid row of the batch in utterance order; `counts` [B].
+    Returns list[B] of list[tuple]: numpy turns a record into a tuple of python scalars in C, the flat list is then cut
+    per utterance.  The cyclic garbage collector is paused meanwhile: the result is ~10^5 tuples, none of them part of a
+    cycle, and every generation-0 pass over them (one per 700 allocations) only costs time."""
+    import gc
+    paused = gc.isenabled()
+    if paused:
+        gc.disable()
+    try:
+        flat = records.tolist()
+        out, lo = [], 0
+        for hi in np.cumsum(counts).tolist():
+            out.append(flat[lo:hi])
+            lo = hi
+        return out
+    finally:
+        if paused:
+            gc.enable()
+
+
 class AlignmentResult:
     """Device-resident result of one batch (no host synchronisation has happened yet)."""
 
@@ -97,14 +121,15 @@ class AlignmentResult:
                                    f"missing, or no-silence was promised although the target contains the silence id)")
 
     def to_lists(self):
-        """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871)."""
-        cnt = self.seg_count.cpu().numpy()
-        segs = self.segs.cpu().numpy()
-        out = []
-        for b in range(cnt.shape[0]):
-            rows = segs[b, :cnt[b]].tolist()
-            out.append([tuple(r) for r in rows])
-        return out
+        """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871).
+        One device-side compaction of the valid rows, ONE copy to the host, one flat list of tuples cut per utterance
+        (a per-utterance `.tolist()` loop cost 76 ms on the 4096-utterance headline batch against 0.35 ms of device time)."""
+        cnt_d = self.seg_count
+        cap = self.segs.shape[1]
+        valid = torch.arange(cap, device=cnt_d.device, dtype=torch.int32).unsqueeze(0) < cnt_d.clamp(max=cap).unsqueeze(1)
+        packed = self.segs[valid].cpu().numpy()         # [sum(count), 4] in utterance order
+        cnt = cnt_d.clamp(max=cap).cpu().numpy()
+        return rows_as_tuple_lists(packed.view(_ROW4).reshape(-1), cnt)
 
 
 class ViterbiDecoder:
@@ -115,7 +140,7 @@ class ViterbiDecoder:
         self.blank_id = blank_id
         self.silence_id = silence_id
         self.silence_anchors = silence_anchors
-        self.min_phoneme_prob = min_phoneme_prob  # the kernels implement the reference default 1e-8 only
+        self.min_phoneme_prob = min_phoneme_prob  # forced_alignment.py:20; its float32 log is the floor (bfa_params.min_log_prob)
         self.ignore_noise = ignore_noise
         self.truly_forced = truly_forced
         self._neg_inf = -1000.0
@@ -134,9 +159,15 @@ class ViterbiDecoder:
     def _params(self, boost_targets, enforce_minimum, anchor_pauses, simple=False, max_blanks=10):
         if self.blank_id is None:
             raise ValueError("Blank ID not set. Call set_blank_id first.")  # forced_alignment.py:104-105
-        if abs(self.min_phoneme_prob - 1e-8) > 0:
-            raise NotImplementedError("min_phoneme_prob other than the reference default 1e-8")
         p = _lib.BfaParams()
+        # forced_alignment.py:70: the floor is torch.log(torch.tensor(min_phoneme_prob)) -- float32, computed by the
+        # caller's own torch so that the kernels compare against the very bits the reference compares against
+        min_log = float(torch.log(torch.tensor(self.min_phoneme_prob, dtype=torch.float32)))
+        if min_log != min_log:  # NaN (negative probability): `x < nan` is never true, the reference floors nothing
+            enforce_minimum = False
+        else:
+            p.has_min_log_prob = 1
+            p.min_log_prob = min_log
         p.blank_id = int(self.blank_id)
         p.silence_id = -1 if self.silence_id is None else int(self.silence_id)
         p.silence_anchors = int(self.silence_anchors) if anchor_pauses else 0
@@ -286,25 +317,14 @@ class ViterbiDecoder:
         return res
 
     def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
-                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0, tail_stream=None):
+                    anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
         """Whole-batch device call (bfa_align_batch).  Returns an AlignmentResult of device tensors; nothing
-        is synchronised or copied to the host here.
-
-        tail_stream (a torch.cuda.Stream): pipelined form (include/bfa.h, bfa_set_tail_stream) -- planning + K1 go to
-        the current stream, the walk / run-length encoding to `tail_stream`, and the current stream does not wait for
-        them: the result tensors are complete on `tail_stream`.  Two decoders (handle_slot 0 / 1: own library handle,
-        workspace and outputs) taking turns keep the K1 of one batch and the tail of the previous one side by side."""
+        is synchronised or copied to the host here."""
         c = self._prepare_call(log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets, enforce_minimum,
                                anchor_pauses, simple, seg_cap, max_blanks, class_mask)
         dev, lp, T_len = c["dev"], c["lp"], c["T_len"]
         L = _lib.lib()
         h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(), self.handle_slot)
-        tail_ptr = tail_stream.cuda_stream if tail_stream is not None else None
-        if tail_ptr is not None or getattr(self, "_tail_ptr", None) is not None:  # (the handle may be shared: set it per call)
-            rc = L.bfa_set_tail_stream(h, tail_ptr)
-            if rc != 0:
-                raise RuntimeError(f"bfa_set_tail_stream failed ({rc}): {L.bfa_last_error(h).decode()}")
-            self._tail_ptr = tail_ptr
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             rc = L.bfa_align_batch(h, lp.data_ptr(), lp.stride(0), lp.stride(1), c["B"], c["Tmax"], c["C"],
@@ -409,13 +429,12 @@ class AlignmentUtils:
                                               ignore_noise=ignore_noise, truly_forced=self.truly_forced)
 
     def decode_alignments_device(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True,
-                                 enforce_minimum=True, seg_cap=None, class_mask=0, tail_stream=None):
-        """decode_alignments without the host round trip: returns an AlignmentResult (device tensors).
-        tail_stream: see ViterbiDecoder.align_batch (pipelined calls)."""
+                                 enforce_minimum=True, seg_cap=None, class_mask=0):
+        """decode_alignments without the host round trip: returns an AlignmentResult (device tensors)."""
         return self.viterbi_decoder.align_batch(log_probs, true_seqs, pred_lens, true_seqs_lens,
                                                 boost_targets=boost_targets, enforce_minimum=enforce_minimum,
                                                 anchor_pauses=self.silence_anchors > 0, seg_cap=seg_cap,
-                                                class_mask=class_mask, tail_stream=tail_stream)
+                                                class_mask=class_mask)
 
     def decode_alignments(self, log_probs, true_seqs=None, pred_lens=None, true_seqs_lens=None,
                           forced_alignment=True, boost_targets=True, enforce_minimum=True, debug=False):
@@ -443,17 +462,20 @@ class AlignmentUtils:
 
 
 def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
-                seg_cap=None):
+                seg_cap=None, class_masks=None):
     """core.py:897-922 from the model's RAW logits for every head in ONE library call (bfa_align_heads): the
     log_softmax of core.py:898-899 is fused into the alignment kernels, no log-prob matrix is written.  `utils_list` are
     the heads' AlignmentUtils (phoneme head first), `logits_list` / `seqs_list` their [B,T,C] logits and [B,S] targets.
     Returns [(AlignmentResult, row_stats [B,T,2]) per head]; later stages take (logits, row_stats) in place of log-probs
-    (calculate_confidences_batch / postprocess_batch `row_stats=`)."""
+    (calculate_confidences_batch / postprocess_batch `row_stats=`).  `class_masks`: per head, the optional
+    bfa_params.class_mask hint (ViterbiDecoder.class_mask_hint) for callers whose lengths live on the device; by default
+    it is derived from host-resident lengths / targets like in align_batch.  The call runs on the library handle of the
+    first head's decoder (`viterbi_decoder.handle_slot`)."""
     calls = []
-    for au, lg, sq in zip(utils_list, logits_list, seqs_list):
+    for k, (au, lg, sq) in enumerate(zip(utils_list, logits_list, seqs_list)):
         vd = au.viterbi_decoder
         c = vd._prepare_call(lg, sq, pred_lens, true_seqs_lens, boost_targets, enforce_minimum,
-                             au.silence_anchors > 0, False, seg_cap, 10, 0)
+                             au.silence_anchors > 0, False, seg_cap, 10, class_masks[k] if class_masks else 0)
         c["stats"] = torch.empty((c["B"], c["Tmax"], 2), dtype=torch.float32, device=c["dev"])
         calls.append(c)
     c0 = calls[0]
@@ -472,7 +494,8 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
         hd.workspace, hd.workspace_bytes = c["ws"].data_ptr(), c["ws"].numel()
     dev = c0["dev"]
     L = _lib.lib()
-    h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+    h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(),
+                    utils_list[0].viterbi_decoder.handle_slot)
     T_len = c0["T_len"]
     with torch.cuda.device(dev):
         rc = L.bfa_align_heads(h, heads, len(calls), c0["B"], c0["Tmax"], T_len.data_ptr() if T_len is not None else None,

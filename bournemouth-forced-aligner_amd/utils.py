@@ -16,8 +16,8 @@ def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None, row_sta
     """Batch form: log_probs [B,T,C] (device), segs int32 [B,seg_cap,4], seg_count int32 [B].
     Returns (conf float32 [B,seg_cap], status int32 [B]) as device tensors; no synchronisation.
     With `row_stats` ([B,T,2] from bfa_align_heads) `log_probs` holds the RAW LOGITS instead.
-    `handle_slot`: the library handle of the decoder that produced `segs` -- needed when that decoder runs pipelined
-    calls (ViterbiDecoder.align_batch(tail_stream=...)): the pass is then ordered behind the call's pending tail."""
+    `handle_slot`: which of the process's library handles to use (the pass itself is stream-ordered on the current
+    stream and keeps no state in the handle)."""
     dev = _device_of(log_probs)
     lp = log_probs.to(device=dev, dtype=torch.float32)
     if lp.stride(2) != 1:

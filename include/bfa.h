@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BFA_ABI_VERSION 2 /* v2: bfa_params hint fields named (same layout as v1's reserved[3]) */
+#define BFA_ABI_VERSION 3 /* v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
 
 typedef struct bfa_context *bfa_handle;
 
@@ -94,6 +94,12 @@ typedef struct {
                                   layout.  Every token costs the path a frame in a blank state, so utterances with more
                                   tokens than this are not tried in the window at all. */
     int32_t window_max_frames; /* 0 = 1536: likewise for long utterances (scores are sums of per-frame log-probs). */
+    /* ---- ViterbiDecoder(min_phoneme_prob=1e-8) (forced_alignment.py:16-20): the floor _enforce_minimum_probabilities
+     * puts under the target columns is torch.log(torch.tensor(min_phoneme_prob)) in float32 (forced_alignment.py:70).
+     * The caller passes that float32 LOGARITHM (its own torch computes it, so the bits are the reference's);
+     * has_min_log_prob = 0 selects the default log(1e-8) = -18.420681f. ---- */
+    int32_t has_min_log_prob;
+    float min_log_prob;
 } bfa_params;
 
 /* one aligned run: assort_frames tuple (phoneme_id, start_frame, end_frame, target_seq_idx),
@@ -199,20 +205,6 @@ typedef struct {
 
 int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int Tmax, const int32_t *T_len,
                     const int32_t *S_len, void *stream);
-
-/*
- * Pipelined calls.  A bfa_align_batch call is planning + K1 (the banded forward pass, ~85 % of a step, which keeps the
- * machine busy) followed by a tail of latency chains (rerun launch, backtrace, run-length encoding, ~15 %).  With a tail
- * stream set, a call enqueues planning + K1 on the caller's stream and the tail on `tail_stream` (behind an event);
- * the caller's stream does NOT wait for the tail, so the K1 of the next call can start while this call's tail runs.
- * The outputs of a call are complete on the TAIL stream (synchronise on it, or make a consumer stream wait for it;
- * bfa_confidences / bfa_postprocess / a later bfa_align_* call on the same handle order themselves behind a pending
- * tail).  A later call on the SAME handle waits for the pending tail before it starts (same workspace): to keep
- * two calls in flight, alternate between two handles with a workspace and an output set each.  Results are identical
- * to the stream-ordered form.  tail_stream = NULL restores it.  (bfa_align_heads ignores the tail stream.)
- * Replaces nothing in the reference: its loop over the batch is sequential (forced_alignment.py:885-905).
- */
-int bfa_set_tail_stream(bfa_handle h, void *tail_stream);
 
 /*
  * Measurement hooks (bench.py): with on = n >= 1, every n-th bfa_align_batch call brackets its K1 launches

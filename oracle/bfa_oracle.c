@@ -13,7 +13,7 @@
 #include <string.h>
 
 #define NEGF (-1000.0f)              /* forced_alignment.py:23  _neg_inf */
-#define MIN_LOGP (-18.420680999755859375f) /* f32 torch.log(tensor(1e-8)) = 0xc1935d8e, forced_alignment.py:70 */
+/* (the default floor log(1e-8) = -18.420681f is the CALLER's ora_params.min_log_prob: oracle.py MIN_LOGP) */
 
 /* ------------------------------------------------------------------------------------------
  * torch-CPU numerics.  F.log_softmax(dim=-1) on a float32 CPU tensor (torch 2.10, AVX512
@@ -284,7 +284,7 @@ int ora_prepare_emissions(const float *lp, long ldT, int T, int C, const int32_t
     if (p->enforce_minimum) { /* :69-81 */
         for (int t = 0; t < T; t++) {
             float *r = out + (long)t * C;
-            for (int c = 0; c < C; c++) if (mask[c] && r[c] < MIN_LOGP) r[c] = MIN_LOGP;
+            for (int c = 0; c < C; c++) if (mask[c] && r[c] < p->min_log_prob) r[c] = p->min_log_prob; /* :79-81 */
         }
     }
     free(mask);

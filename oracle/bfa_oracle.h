@@ -40,6 +40,7 @@ typedef struct {
     int32_t truly_forced;
     int32_t boost_targets;
     int32_t enforce_minimum;
+    float min_log_prob;      /* float32 torch.log(torch.tensor(min_phoneme_prob)), forced_alignment.py:70 (default log 1e-8) */
 } ora_params;
 
 /* torch CPU (AVX512 dispatch) numerics, restated: Sleef expf/logf u10 and the

@@ -20,14 +20,17 @@ MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 class Params(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "blank_id", "silence_id", "silence_anchors", "ignore_noise", "truly_forced",
-        "boost_targets", "enforce_minimum")]
+        "boost_targets", "enforce_minimum")] + [("min_log_prob", ctypes.c_float)]
+
+MIN_LOGP = -18.420680999755859375  # float32 torch.log(torch.tensor(1e-8)), forced_alignment.py:70
 
 
 def make_params(blank_id, silence_id=0, silence_anchors=10, ignore_noise=True, truly_forced=True,
-                boost_targets=True, enforce_minimum=True):
+                boost_targets=True, enforce_minimum=True, min_log_prob=MIN_LOGP):
+    """min_log_prob: the float32 logarithm of ViterbiDecoder.min_phoneme_prob as the caller's torch computes it"""
     return Params(int(blank_id), -1 if silence_id is None else int(silence_id), int(silence_anchors),
                   int(bool(ignore_noise)), int(bool(truly_forced)), int(bool(boost_targets)),
-                  int(bool(enforce_minimum)))
+                  int(bool(enforce_minimum)), float(min_log_prob))
 
 
 def build(force=False):

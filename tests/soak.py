@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""tests/soak.py [n_batches] [seed] -- randomized differential soak of the HIP path against the CPU oracle
-(run on the GPU box).  Every batch draws its own head width, flags, length ranges and posterior sharpness;
-integer outputs must be identical.  Not part of pytest (minutes); prints one line per mismatch and a summary."""
+"""tests/soak.py [n_batches] [seed] [--record file.json] -- randomized differential soak of the HIP path against the CPU
+oracle (run on the GPU box).  Every batch draws its own head width, flags, floor probability, length ranges and posterior
+sharpness; integer outputs must be identical.  `run()` is what `pytest -m gpu` calls on a fixed-seed slice
+(tests/test_gpu_parity.py::test_soak_slice); the full soak takes minutes, prints one line per mismatch and a summary, and
+with --record appends its per-seed counts to a JSON file (profiles/r03_soak.json)."""
 import os
 import sys
 import time
@@ -17,11 +19,10 @@ from oracle import oracle as ora  # noqa: E402
 from bournemouth_forced_aligner_amd import AlignmentUtils  # noqa: E402
 
 
-def main():
-    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(nb=200, seed=1, dev=None):
+    """Returns {"seed", "batches", "utterances", "mismatching", "post_dp_mismatches", "fused_mismatches", "seconds"}."""
     rng = np.random.default_rng(seed)
-    dev = torch.device("cuda", 0)
+    dev = dev or torch.device("cuda", 0)
     bad = 0
     bad2 = 0
     bad3 = 0
@@ -36,6 +37,7 @@ def main():
         simple = bool(rng.integers(0, 8) == 0)
         boost = bool(rng.integers(0, 6) != 0)
         enf = bool(rng.integers(0, 6) != 0)
+        min_prob = float(rng.choice([1e-8, 1e-8, 1e-8, 1e-4, 0.05]))  # ViterbiDecoder.min_phoneme_prob (forced_alignment.py:20)
         regime = int(rng.integers(0, 5))
         n = int(rng.integers(4, 40))
         lps, toks = [], []
@@ -57,6 +59,8 @@ def main():
             lps.append(lp); toks.append(tk)
         lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
         au = AlignmentUtils(blank, 0, silence_anchors=anchors, ignore_noise=ign, truly_forced=tf)
+        au.viterbi_decoder.min_phoneme_prob = min_prob
+        min_log = float(torch.log(torch.tensor(min_prob, dtype=torch.float32)))  # the float32 floor, forced_alignment.py:70
         au.viterbi_decoder.window_max_tokens = None if rng.integers(0, 2) else 4096
         hint = None if rng.integers(0, 2) else 0   # None: no hint at all; 0: derived by align_batch from the host lengths
         if rng.integers(0, 2):
@@ -76,7 +80,7 @@ def main():
                                              boost_targets=boost, enforce_minimum=enf, anchor_pauses=anchors > 0,
                                              simple=simple, seg_cap=lp.shape[1] + 1, class_mask=hint)
         torch.cuda.synchronize()
-        prm = ora.make_params(blank, 0, anchors, ign, tf, boost, enf)
+        prm = ora.make_params(blank, 0, anchors, ign, tf, boost, enf, min_log_prob=min_log)
         exp = ora.decode_alignments(lp, tk, T_len, S_len, prm, simple=simple)
         st = res.status.cpu().numpy()
         fph = res.frame_phonemes.cpu().numpy(); fidx = res.frame_phonemes_idx.cpu().numpy()
@@ -96,7 +100,7 @@ def main():
                                     ign=ign, simple=simple, boost=boost, enf=enf, got_ph=fph[b], got_idx=fidx[b],
                                     exp_ph=exp["frame_ph"][b], exp_idx=exp["frame_idx"][b], mode=exp["mode"][b])
                 print(f"MISMATCH batch {it} item {b}: C={C} T={int(T_len[b])} S={int(S_len[b])} anchors={anchors} tf={tf} ign={ign} "
-                      f"simple={simple} boost={boost} enf={enf} hint={hint} status={st[b]}/{exp['status'][b]}", flush=True)
+                      f"simple={simple} boost={boost} enf={enf} min_prob={min_prob} hint={hint} status={st[b]}/{exp['status'][b]}", flush=True)
         # ---- post-DP stages on the GPU's own tuples: confidences (utils.py:70-113), then ensure_target_coverage
         # (default) + extend_soft_boundaries (core.py:925-931)
         if (st == 0).all() and n > 0:
@@ -168,7 +172,35 @@ def main():
                 print(f"FUSED-vs-TWO-PASS MISMATCH batch {it}: C={C} anchors={anchors} tf={tf} ign={ign} boost={boost} enf={enf} regime={regime} {why}", flush=True)
     print(f"soak: {items} utterances in {nb} batches, {bad} mismatching, {bad2} post-DP mismatches, "
           f"{bad3} fused-front-end mismatches, {time.time() - t0:.0f} s (seed {seed})")
-    return 1 if (bad or bad2 or bad3) else 0
+    return {"seed": seed, "batches": nb, "utterances": items, "mismatching": bad, "post_dp_mismatches": bad2,
+            "fused_mismatches": bad3, "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    argv = [a for a in sys.argv[1:]]
+    record = None
+    if "--record" in argv:
+        k = argv.index("--record")
+        record = argv[k + 1]
+        del argv[k:k + 2]
+    nb = int(argv[0]) if len(argv) > 0 else 200
+    seed = int(argv[1]) if len(argv) > 1 else 1
+    out = run(nb, seed)
+    if record:
+        import json
+        try:
+            with open(record) as f:
+                doc = json.load(f)
+        except Exception:
+            doc = {"what": "tests/soak.py: randomized differential soak of the HIP path against the CPU oracle, per seed",
+                   "runs": []}
+        doc["runs"].append(out)
+        doc["total_utterances"] = sum(r["utterances"] for r in doc["runs"])
+        doc["total_mismatches"] = sum(r["mismatching"] + r["post_dp_mismatches"] + r["fused_mismatches"] for r in doc["runs"])
+        os.makedirs(os.path.dirname(os.path.abspath(record)), exist_ok=True)
+        with open(record, "w") as f:
+            json.dump(doc, f, indent=1)
+    return 1 if (out["mismatching"] or out["post_dp_mismatches"] or out["fused_mismatches"]) else 0
 
 
 if __name__ == "__main__":

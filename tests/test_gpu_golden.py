@@ -50,6 +50,27 @@ def test_hotpath_cases_against_reference(gold, gpu_device):
             np.testing.assert_array_equal(np.array([[c[1], c[2]] for c in cf], np.int32), gold[f"c{i}_conf_se"])
 
 
+def test_min_phoneme_prob_against_reference(gpu_device):
+    """ViterbiDecoder.min_phoneme_prob other than 1e-8 (forced_alignment.py:16-20,70; bfa_params.min_log_prob): tuples,
+    framewise states and the prepared emissions' bit patterns against the reference's own outputs
+    (tests/golden/make_golden_minprob.py), C = 67 and 17, probabilities 1e-8 / 1e-4 / 1e-2 / 0.5 / 1e-20 / 0."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "minprob_cases.npz"))
+    meta = json.loads(str(g["meta"]))
+    for i, m in enumerate(meta):
+        lp = torch.from_numpy(g[f"m{i}_lp"]).to(gpu_device)
+        tk = torch.from_numpy(g[f"m{i}_tok"].astype(np.int64))
+        au = AlignmentUtils(m["blank"], 0, silence_anchors=10, ignore_noise=True, truly_forced=m["truly_forced"])
+        au.viterbi_decoder.min_phoneme_prob = m["prob"]   # (how a caller of the reference changes it, forced_alignment.py:850)
+        segs = au.decode_alignments(lp[None], tk[None], torch.tensor([m["T"]]), torch.tensor([m["S"]]))[0]
+        np.testing.assert_array_equal(np.array(segs, np.int32).reshape(-1, 4), g[f"m{i}_seg"], err_msg=f"case {i} {m}")
+        fp, fi, _ = au.viterbi_decoder.decode_with_forced_alignment(lp, tk)
+        np.testing.assert_array_equal(fp.cpu().numpy(), g[f"m{i}_fph"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(fi.cpu().numpy(), g[f"m{i}_fidx"], err_msg=f"case {i}")
+        mod = au.viterbi_decoder.prepare_emissions(lp[None], tk[None], [m["T"]], [m["S"]])[0].cpu().numpy()
+        assert (mod.view(np.int32) == g[f"m{i}_mod"].view(np.int32)).all(), f"case {i}: prepared emissions differ"
+
+
 def test_log_softmax_against_torch_bits(gold, gpu_device):
     from bournemouth_forced_aligner_amd import log_softmax
     for C in (67, 17):

@@ -200,3 +200,29 @@ def test_level2_large_fixture(ora):
                 n += len(conf)
                 exact += int((conf.view(np.int32) == gf[:, 0].copy().view(np.int32)).sum())
     assert n == 2670 and exact > 0.9 * n, (n, exact)
+
+
+def test_min_phoneme_prob_matches_reference(ora):
+    """ViterbiDecoder.min_phoneme_prob other than 1e-8 (forced_alignment.py:16-20,70): the floor is the float32 logarithm
+    torch computed (stored in the fixture); tuples, framewise states and the modified log-probs' bits must be the
+    reference's (tests/golden/make_golden_minprob.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "minprob_cases.npz"))
+    meta = json.loads(str(g["meta"]))
+    floors = set()
+    n_floor_matters = 0
+    for i, m in enumerate(meta):
+        lp, tk = g[f"m{i}_lp"], g[f"m{i}_tok"]
+        minlog = float(g[f"m{i}_minlog"][0])
+        floors.add(minlog)
+        prm = ora.make_params(m["blank"], 0, 10, True, m["truly_forced"], True, True, min_log_prob=minlog)
+        res = ora.decode_alignments(lp[None], tk[None], [m["T"]], [m["S"]], prm)
+        assert res["status"][0] == 0
+        got = np.array(ora.segments_as_lists(res)[0], np.int32).reshape(-1, 4)
+        np.testing.assert_array_equal(got, g[f"m{i}_seg"], err_msg=f"case {i} {m}")
+        np.testing.assert_array_equal(res["frame_ph"][0, :m["T"]], g[f"m{i}_fph"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(res["frame_idx"][0, :m["T"]], g[f"m{i}_fidx"], err_msg=f"case {i}")
+        rc, mod = ora.prepare_emissions(lp, tk, prm)
+        assert rc == 0 and (mod.view(np.int32) == g[f"m{i}_mod"].view(np.int32)).all(), f"case {i}"
+        _, mod_default = ora.prepare_emissions(lp, tk, ora.make_params(m["blank"], 0, 10, True, m["truly_forced"]))
+        n_floor_matters += int(not np.array_equal(mod, mod_default))
+    assert len(floors) == 6 and n_floor_matters >= 16  # the non-default floors do change the emissions

@@ -176,3 +176,45 @@ def synth_ragged(B, Tlo, Thi, C, seed, device, peak=9.0):
     logits.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, Tmax, 1), peak, device=device))
     lp = torch.log_softmax(logits, dim=-1)
     return lp, toks.to(torch.int32), T_len.to(torch.int32), S_len.to(torch.int32)
+
+
+def group_lut(device=None):
+    """phoneme id -> group id of the synthetic "real text" workload: SIL (0) -> silence group 0, phonemes 1..65 ->
+    groups 1..15, blank 66 -> blank group 16 (the shape of the reference's phoneme_id_to_group_id, core.py:868-871)."""
+    lut = torch.tensor([0] + [1 + p % 15 for p in range(1, 66)] + [16], dtype=torch.int64)
+    return lut if device is None else lut.to(device)
+
+
+def synth_realtext(B, T, S, seed, device, sil_rate=1.0 / 12, sil_len=(12, 40), peak=9.0, gpeak=7.0):
+    """What real transcripts give the aligner (SURVEY.md section 8(d) "-sil" variant, core.py:897-922): RAW logits of both
+    heads (ph66: C = 67, blank 66; groups: C = 17, blank 16), targets with SIL (id 0) at ~`sil_rate` of the positions
+    (punctuation -> SIL, ph66_phonemeizer.py:185-199) and a planted silence of sil_len frames for each, >= 2 frames per
+    other token, blank elsewhere; logits = N(0,1) + peak * onehot(planted).  The group targets are the phoneme targets
+    through `group_lut`.  Returns (logits_p [B,T,67], logits_g [B,T,17], tokens [B,S] i32, group_tokens [B,S] i32)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    blank = 66
+    toks = torch.randint(1, blank, (B, S), generator=g, device=device)
+    is_sil = torch.rand((B, S), generator=g, device=device) < sil_rate
+    toks = torch.where(is_sil, torch.zeros_like(toks), toks)
+    sil_frames = torch.randint(sil_len[0], sil_len[1] + 1, (B, S), generator=g, device=device)
+    want = torch.where(is_sil, sil_frames, torch.full_like(sil_frames, 2))
+    extra = (T - want.sum(dim=1, keepdim=True))
+    assert int(extra.min()) >= 0, "the planted tokens do not fit into T frames"
+    u = torch.rand((B, 2 * S), generator=g, device=device)
+    cuts, _ = torch.sort(torch.floor(u * (extra + 1).to(u.dtype)).to(torch.int64), dim=1)
+    zeros = torch.zeros((B, 1), dtype=torch.int64, device=device)
+    sizes = torch.diff(torch.cat([zeros, cuts, extra], dim=1), dim=1)  # gap,tok,gap,tok,...,gap
+    sizes[:, 1::2] += want
+    ends = torch.cumsum(sizes, dim=1)
+    t = torch.arange(T, device=device).unsqueeze(0).expand(B, T).contiguous()
+    slot = torch.searchsorted(ends, t, right=True)
+    is_tok = (slot % 2) == 1
+    tok_idx = torch.clamp((slot - 1) // 2, 0, S - 1)
+    planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
+    lut = group_lut(device)
+    logits_p = torch.randn((B, T, 67), generator=g, device=device, dtype=torch.float32)
+    logits_p.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, T, 1), peak, device=device))
+    logits_g = torch.randn((B, T, 17), generator=g, device=device, dtype=torch.float32)
+    logits_g.scatter_add_(2, lut[planted].unsqueeze(-1), torch.full((B, T, 1), gpeak, device=device))
+    return logits_p, logits_g, toks.to(torch.int32), lut[toks].to(torch.int32)
