@@ -710,8 +710,9 @@ def realtext_main(args, rk):
     """`--config realtext`: what the reference does with a REAL transcript (core.py:897-937): raw logits of both heads
     (ph66 C = 67, groups C = 17), targets with SIL (punctuation) -> the silence-anchored segmented mode
     (forced_alignment.py:268-469) in both heads, then coverage + soft boundaries (core.py:925-931) and confidences
-    (core.py:936-937) per head.  One step = bfa_align_heads -> bfa_postprocess x2 -> bfa_confidences x2 on device-resident
-    logits; nothing synchronises inside a step.  Parity: the first `--parity-sample` utterances of the batch through
+    (core.py:936-937) per head.  One step = ONE bfa_align_heads call with the post-DP stages of each head enqueued behind
+    its alignment (bfa_postprocess / bfa_confidences on the head's stream) on device-resident logits; nothing synchronises
+    inside a step.  Parity: the first `--parity-sample` utterances of the batch through
     the oracle's whole chain (log_softmax -> decode -> coverage -> soft boundaries -> confidences), both heads."""
     from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch, _lib
     from bournemouth_forced_aligner_amd.forced_alignment import align_heads
@@ -740,13 +741,17 @@ def realtext_main(args, rk):
 
     def one(ap, ag, buf):
         xp, xg, tp, tg = buf
-        (rp, sp), (rg, sg) = align_heads([ap, ag], [xp, xg], [tp, tg], T_len, S_len, class_masks=hints)
-        out = []
-        for x, r, st in ((xp, rp, sp), (xg, rg, sg)):
-            postprocess_batch(x, S_len, r.segs, r.seg_count, extend=True, boundary_softness=soft, row_stats=st)
-            cf, cs = calculate_confidences_batch(x, r.segs, r.seg_count, row_stats=st)
-            out.append((r, cf, cs))
-        return out
+        if args.separate_post:  # A/B: the post-DP stages as separate calls behind the joined alignment (round 2's order)
+            (rp, sp), (rg, sg) = align_heads([ap, ag], [xp, xg], [tp, tg], T_len, S_len, class_masks=hints)
+            out = []
+            for x, r, st in ((xp, rp, sp), (xg, rg, sg)):
+                postprocess_batch(x, S_len, r.segs, r.seg_count, extend=True, boundary_softness=soft, row_stats=st)
+                cf, cs = calculate_confidences_batch(x, r.segs, r.seg_count, row_stats=st)
+                out.append((r, cf, cs))
+            return out
+        (rp, _sp), (rg, _sg) = align_heads([ap, ag], [xp, xg], [tp, tg], T_len, S_len, class_masks=hints,
+                                           post={"extend": True, "boundary_softness": soft})
+        return [(rp, rp.conf, rp.conf_status), (rg, rg.conf, rg.conf_status)]
 
     def run_steps(n):
         for _ in range(n):
@@ -923,6 +928,8 @@ def main():
                     help="the reported figure covers ceil(this / --steps) windows of exactly --steps steps (SURVEY 8(d): >= 100)")
     ap.add_argument("--kernel-leg-steps", type=int, default=40,
                     help="headline: steps of the one-batch-in-flight leg that prices the kernel for `roofline`")
+    ap.add_argument("--separate-post", action="store_true",
+                    help="realtext A/B: bfa_postprocess / bfa_confidences as separate calls after bfa_align_heads")
     ap.add_argument("--row-pitch", type=int, default=0,
                     help="headline A/B: posterior rows padded to this many floats (e.g. 72 = 288-byte rows), 0 = dense")
     ap.add_argument("--tlo", type=int, default=200, help="--ragged: shortest utterance")

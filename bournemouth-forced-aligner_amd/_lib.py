@@ -35,7 +35,9 @@ class BfaHead(ctypes.Structure):
                 ("out_row_stats", ctypes.c_void_p), ("out_frame_phoneme", ctypes.c_void_p),
                 ("out_frame_idx", ctypes.c_void_p), ("out_segs", ctypes.c_void_p), ("seg_cap", ctypes.c_int32),
                 ("out_seg_count", ctypes.c_void_p), ("out_status", ctypes.c_void_p), ("out_mode", ctypes.c_void_p),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("postprocess", ctypes.c_int32), ("extend", ctypes.c_int32), ("boundary_softness", ctypes.c_int32),
+                ("out_conf", ctypes.c_void_p), ("out_conf_status", ctypes.c_void_p)]
 
 
 class BfaSegment(ctypes.Structure):

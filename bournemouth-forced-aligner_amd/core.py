@@ -189,6 +189,8 @@ class PhonemeTimestampAligner:
             res.segs.copy_(torch.from_numpy(host))
             res.seg_count.copy_(torch.tensor([len(rs) for rs in rows], dtype=torch.int32))
             estimated = [[bool(r[4]) for r in rs] for rs in rows]
+        if res.conf is not None:  # the fused call already ran coverage / soft boundaries / confidences on the head's stream
+            return res, res.conf, res.conf_status, estimated
         postprocess_batch(log_probs, seq_lens, res.segs, res.seg_count, extend=self.extend_soft_boundaries,
                           boundary_softness=self.boundary_softness, row_stats=stats)
         conf, cstat = calculate_confidences_batch(log_probs, res.segs, res.seg_count, row_stats=stats)  # padded rows (core.py:936)
@@ -231,8 +233,11 @@ class PhonemeTimestampAligner:
             # kernels, both heads from one bfa_align_heads call; the later stages read (logits, row statistics)
             xs = [logits_class.to(device=dev, dtype=torch.float32), logits_group.to(device=dev, dtype=torch.float32)]
             us = [self.alignment_utils_p, self.alignment_utils_g]
+            # (with ensure_completeness the host-side repair sits between the alignment and the post-DP stages)
+            post = None if self.ensure_completeness else {"extend": self.extend_soft_boundaries,
+                                                          "boundary_softness": self.boundary_softness}
             aligned = align_heads(us, xs, [ph, gr], spec, ph_seq_lens, boost_targets=self.boost_targets,
-                                  enforce_minimum=self.enforce_minimum)
+                                  enforce_minimum=self.enforce_minimum, post=post)
             pending = [(key, self._head(u, x, sq, ph_seq_lens, spec, aligned=al))
                        for key, u, x, sq, al in zip(("phoneme_timestamps", "group_timestamps"), us, xs, [ph, gr], aligned)]
         else:

@@ -192,7 +192,18 @@ int bfa_create(bfa_handle *out, int device)
             if (ok) h->naux = k + 1;
         }
         const char *serial = getenv("BFA_HEADS_SERIAL"); // (measurement switch: heads one after the other)
-        if (!(serial && serial[0] == '1') && hipStreamCreateWithFlags(&h->head_stream, hipStreamNonBlocking) == hipSuccess) {
+        // The runtime maps the streams of one priority onto a few hardware queues (four by default), and a queue runs its
+        // kernels in order: created like the auxiliary streams, this stream landed on the CALLER's queue and the heads
+        // ran one behind the other (profiles/r03_realtext_timeline_before.txt).  A stream of another priority gets a queue
+        // of its own; the later heads are the narrow ones (group head: C = 17), which fill in beside the phoneme head.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // (numerically: lowest priority = largest value)
+        const char *hp = getenv("BFA_HEAD_PRIO"); // (measurement switch: "normal" / "high"; default low)
+        int head_prio = prio_lo;
+        if (hp && hp[0] == 'n') head_prio = 0;
+        if (hp && hp[0] == 'h') head_prio = prio_hi;
+        if (!(serial && serial[0] == '1') &&
+            hipStreamCreateWithPriority(&h->head_stream, hipStreamNonBlocking, head_prio) == hipSuccess) {
             if (hipEventCreateWithFlags(&h->head_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->head_join, hipEventDisableTiming) != hipSuccess) {
                 (void)hipStreamDestroy(h->head_stream);
@@ -379,6 +390,13 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
         rc = align_impl(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, T_len, hd.tokens, S_len,
                         hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
                         hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st);
+        // core.py:925-937 for this head on ITS stream: coverage + soft boundaries, then the confidences of the final tuples
+        if (rc == BFA_OK && hd.postprocess)
+            rc = bfa_postprocess(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, S_len, hd.out_segs,
+                                 hd.seg_cap, hd.out_seg_count, hd.extend, hd.boundary_softness, st);
+        if (rc == BFA_OK && hd.out_conf)
+            rc = bfa_confidences(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, nullptr, hd.out_segs,
+                                 hd.seg_cap, hd.out_seg_count, hd.out_conf, hd.out_conf_status, st);
     }
     if (side) {
         (void)hipEventRecord(h->head_join, h->head_stream);

@@ -354,7 +354,10 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
     // one kernel per class; with more than one class to launch they run side by side on the auxiliary streams
-    const int n_kernels = __builtin_popcount(mask & 0xf7fu) + (Lmax > 1024 ? 1 : 0);
+    // (silence-anchored mode on the two head widths: the narrow classes are one launch on the caller's stream, bfa_dp3.inc)
+    const bool merged_narrow = mode == 1 && (a.C == 67 || a.C == 17);
+    const unsigned kmask = merged_narrow ? (mask & ~(3u | (7u << 8))) : mask;
+    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + ((merged_narrow && (mask & (3u | (7u << 8)))) ? 1 : 0) + (Lmax > 1024 ? 1 : 0);
     LaunchFan fan;
     fan.main_stream = stream;
     fan.aux = (hipStream_t *)aux_streams;

@@ -96,6 +96,8 @@ class AlignmentResult:
         self.frame_phonemes_idx = frame_idx
         self.T_len = T_len
         self.S_len = S_len
+        self.conf = None         # float32 [B, seg_cap] / int32 [B]: only when the call also ran the post-DP stages
+        self.conf_status = None  # (align_heads(post=...))
 
     def raise_for_status(self):
         """Reproduce the reference's exceptions (they abort the whole call)."""
@@ -462,7 +464,7 @@ class AlignmentUtils:
 
 
 def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
-                seg_cap=None, class_masks=None):
+                seg_cap=None, class_masks=None, post=None):
     """core.py:897-922 from the model's RAW logits for every head in ONE library call (bfa_align_heads): the
     log_softmax of core.py:898-899 is fused into the alignment kernels, no log-prob matrix is written.  `utils_list` are
     the heads' AlignmentUtils (phoneme head first), `logits_list` / `seqs_list` their [B,T,C] logits and [B,S] targets.
@@ -470,7 +472,11 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
     (calculate_confidences_batch / postprocess_batch `row_stats=`).  `class_masks`: per head, the optional
     bfa_params.class_mask hint (ViterbiDecoder.class_mask_hint) for callers whose lengths live on the device; by default
     it is derived from host-resident lengths / targets like in align_batch.  The call runs on the library handle of the
-    first head's decoder (`viterbi_decoder.handle_slot`)."""
+    first head's decoder (`viterbi_decoder.handle_slot`).
+    `post` = {"extend": bool, "boundary_softness": int, "confidences": bool}: the post-DP stages of every head
+    (core.py:925-937: coverage + soft boundaries in place on the result's segs / seg_count, then the confidences of the final
+    tuples) are enqueued by the same library call right behind each head's alignment on the stream that head runs on, so
+    that they overlap the other head's alignment; the result then carries `.conf` [B,seg_cap] / `.conf_status` [B]."""
     calls = []
     for k, (au, lg, sq) in enumerate(zip(utils_list, logits_list, seqs_list)):
         vd = au.viterbi_decoder
@@ -492,6 +498,13 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
         hd.out_segs, hd.seg_cap = c["segs"].data_ptr(), c["seg_cap"]
         hd.out_seg_count, hd.out_status, hd.out_mode = c["seg_count"].data_ptr(), c["status"].data_ptr(), c["mode"].data_ptr()
         hd.workspace, hd.workspace_bytes = c["ws"].data_ptr(), c["ws"].numel()
+        if post is not None:
+            hd.postprocess, hd.extend = 1, int(bool(post.get("extend", True)))
+            hd.boundary_softness = int(post.get("boundary_softness", 3))
+            if post.get("confidences", True):
+                c["conf"] = torch.zeros((c["B"], c["seg_cap"]), dtype=torch.float32, device=c["dev"])
+                c["cstat"] = torch.zeros((c["B"],), dtype=torch.int32, device=c["dev"])
+                hd.out_conf, hd.out_conf_status = c["conf"].data_ptr(), c["cstat"].data_ptr()
     dev = c0["dev"]
     L = _lib.lib()
     h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(),
@@ -501,4 +514,9 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
         rc = L.bfa_align_heads(h, heads, len(calls), c0["B"], c0["Tmax"], T_len.data_ptr() if T_len is not None else None,
                                c0["S_len"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, h, "bfa_align_heads")
-    return [(ViterbiDecoder._result(c), c["stats"]) for c in calls]
+    out = []
+    for c in calls:
+        res = ViterbiDecoder._result(c)
+        res.conf, res.conf_status = c.get("conf"), c.get("cstat")
+        out.append((res, c["stats"]))
+    return out

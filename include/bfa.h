@@ -183,7 +183,8 @@ int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t s
  * matrix is ever written: K1 normalises each 16-row block in registers (bit-identical to torch's CPU log_softmax),
  * goes on to boost / floor / DP with it, and leaves the row's (maximum, log-sum) pair in out_row_stats, from which
  * bfa_confidences / bfa_postprocess reconstitute the few log-probs they touch as (x - max) - logsum -- the same two
- * float32 subtractions.  Heads after the first run on a stream of the handle, forked from and joined into `stream`.
+ * float32 subtractions.  Heads after the first run on a stream of the handle, forked from and joined into `stream`
+ * (together with their optional post-DP stages, see the last fields of bfa_head).
  * T_len / S_len are shared by the heads (core.py:874-876); everything else is per head.
  */
 typedef struct {
@@ -201,6 +202,14 @@ typedef struct {
     int32_t *out_seg_count, *out_status, *out_mode; /* [B] ; out_mode may be NULL */
     void *workspace;            /* bfa_workspace_bytes(B, Tmax, Smax, C, &params); one per head */
     size_t workspace_bytes;
+    /* ---- optional post-DP stages of this head (core.py:925-937), enqueued right behind its alignment on the stream the
+     * head runs on, so that the stages of one head overlap the alignment of the others:
+     *   postprocess != 0 : bfa_postprocess(extend, boundary_softness) in place on out_segs / out_seg_count;
+     *   out_conf != NULL : bfa_confidences on the resulting tuples -> out_conf [B,seg_cap] float32, out_conf_status [B]
+     *                      (may be NULL); the padded Tmax rows count as in core.py:936.  All zero = alignment only. ---- */
+    int32_t postprocess, extend, boundary_softness;
+    float *out_conf;
+    int32_t *out_conf_status;
 } bfa_head;
 
 int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int Tmax, const int32_t *T_len,
