@@ -381,7 +381,8 @@ def headline_main(args, rk):
             "config": {"workload": f"batch={B} T={T} |tokens|={S} ph66 (C={C}) per GPU, reference-default flags "
                                    f"(boost+floor+truly_forced, anchors=10, no SIL in targets -> standard mode)",
                        "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective",
-                       "batches_in_flight": inflight, "row_pitch_floats": args.row_pitch or C},
+                       "batches_in_flight": inflight, "row_pitch_floats": args.row_pitch or C,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")},
             "timing": {"what": f"{n_windows} windows of exactly {K} steps, each bracketed by barrier + synchronize on both "
                                f"sides (max over ranks); value = frames of all windows / sum of the window times",
                        "windows": n_windows, "timed_steps_total": total_steps,
@@ -721,7 +722,7 @@ def realtext_main(args, rk):
     dev, rank, world = rk.dev, rk.rank, rk.world
     B, T, S = args.batch, args.frames, args.tokens
     K = args.steps
-    nfl = max(1, args.inflight or 1)
+    nfl = max(1, args.inflight if args.inflight is not None else 3)
     nbuf = max(2, nfl)
     bufs = [synth_realtext(B, T, S, 2003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
     T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -807,7 +808,8 @@ def realtext_main(args, rk):
                                    f"logits, SIL at ~1/12 of the target positions with planted 12-40-frame silences, "
                                    f"reference-default flags; step = bfa_align_heads + bfa_postprocess x2 + "
                                    f"bfa_confidences x2; {nfl} step(s) in flight",
-                       "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+                       "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective",
+                       "steps_in_flight": nfl, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")},
             "timing": {"windows": n_windows, "timed_steps_total": total_steps,
                        "window_ms_per_step": {"mean": float(np.mean(win_ms)), "min": float(np.min(win_ms)),
                                               "max": float(np.max(win_ms)), "all": win_ms},
@@ -928,6 +930,10 @@ def main():
                     help="the reported figure covers ceil(this / --steps) windows of exactly --steps steps (SURVEY 8(d): >= 100)")
     ap.add_argument("--kernel-leg-steps", type=int, default=40,
                     help="headline: steps of the one-batch-in-flight leg that prices the kernel for `roofline`")
+    ap.add_argument("--hw-queues", type=int, default=None,
+                    help="GPU_MAX_HW_QUEUES for this process (the runtime maps HIP streams onto this many hardware queues, "
+                         "default 4; read once at HIP initialisation).  Default: 8 for --config realtext (two heads x "
+                         "several steps in flight are more chains than four queues), the runtime's own default otherwise")
     ap.add_argument("--separate-post", action="store_true",
                     help="realtext A/B: bfa_postprocess / bfa_confidences as separate calls after bfa_align_heads")
     ap.add_argument("--row-pitch", type=int, default=0,
@@ -961,6 +967,11 @@ def main():
                     help="initialise the process group even at world size 1 (exercises the N > 1 code path of the headline mode)")
     args = ap.parse_args()
 
+    # the hardware-queue count is a runtime setting read when HIP initialises (nothing has touched the device yet)
+    if args.hw_queues is None and args.config == "realtext":
+        args.hw_queues = 8
+    if args.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
 

@@ -25,6 +25,12 @@ extern "C" int bfa_launch_stitch(const float *win, int B, int NW, int F, int C, 
 extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
                                       const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count,
                                       int extend, double th1, double th2, void *stream);
+// the same stages and / or the confidence pass with the probabilities staged in LDS (bfa_post.hip); -1: shapes do not fit
+extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                                   const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int do_post,
+                                   int extend, double th1, double th2, int do_conf, const int32_t *T_rows, float *conf,
+                                   int32_t *status, void *stream);
+static bool staged_post() { static const bool on = [] { const char *e = getenv("BFA_POST_STAGED"); return !(e && e[0] == '0'); }(); return on; } // (measurement switch)
 
 struct bfa_context {
     int device;
@@ -391,6 +397,15 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
                         hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
                         hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st);
         // core.py:925-937 for this head on ITS stream: coverage + soft boundaries, then the confidences of the final tuples
+        // -- in ONE kernel when both are asked for and the shapes fit its LDS staging (bfa_post.hip: k_postconf)
+        if (rc == BFA_OK && hd.postprocess && hd.out_conf && staged_post() && hd.seg_cap <= 6500) {
+            const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)hd.boundary_softness);
+            const int lrc = bfa_launch_postconf(hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, S_len, hd.out_segs,
+                                                hd.seg_cap, hd.out_seg_count, 1, hd.extend, th1, th2, 1, nullptr, hd.out_conf,
+                                                hd.out_conf_status, st);
+            if (lrc == 0) continue;
+            if (lrc > 0) { rc = fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)lrc)); break; }
+        }
         if (rc == BFA_OK && hd.postprocess)
             rc = bfa_postprocess(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, S_len, hd.out_segs,
                                  hd.seg_cap, hd.out_seg_count, hd.extend, hd.boundary_softness, st);
@@ -446,6 +461,13 @@ int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t s
     DeviceGuard guard(h);
     if (!logp || !segs || !seg_count || !out_conf) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
+    if (staged_post()) { // the probabilities staged in LDS (k_postconf); falls through when the shapes do not fit
+        const int lrc = bfa_launch_postconf(logp, row_stats, strideB, strideT, B, Tmax, C, nullptr, const_cast<bfa_segment *>(segs),
+                                            seg_cap, const_cast<int32_t *>(seg_count), 0, 0, 0.0, 0.0, 1, T_rows, out_conf,
+                                            out_item_status, stream);
+        if (lrc == 0) return BFA_OK;
+        if (lrc > 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)lrc));
+    }
     bfa::ConfArgs a;
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.T_rows = T_rows;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.conf = out_conf; a.status = out_item_status;
@@ -465,6 +487,12 @@ int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t s
     if (seg_cap > 6500) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 6500 in bfa_postprocess (24 bytes of LDS per tuple)");
     // core.py:699-701 : python `10.0 ** -n` is libm pow on doubles
     const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)boundary_softness);
+    if (staged_post()) {
+        const int lrc = bfa_launch_postconf(logp, row_stats, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, 1, extend,
+                                            th1, th2, 0, nullptr, nullptr, nullptr, stream);
+        if (lrc == 0) return BFA_OK;
+        if (lrc > 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)lrc));
+    }
     const int rc = bfa_launch_postprocess(logp, row_stats, strideB, strideT, B, Tmax, C, S_len, segs, seg_cap, seg_count, extend,
                                           th1, th2, stream);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));

@@ -149,6 +149,323 @@ __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
     }
 }
 
+
+// =====================================================================================================================
+// k_postconf: the post-DP stages AND the confidence pass of one utterance with the probabilities they look at STAGED IN
+// LDS.  Both stages read exp(log_prob[f, phoneme]) for the frames of a tuple and a few frames around it -- one element
+// per 268-byte row.  Written tuple-per-lane against global memory (k_postprocess, k_conf) every probe of the four
+// extension passes is a dependent load, and a step costs a full memory round trip: 0.19 + 0.10 ms per 4096-utterance
+// batch with 12-40-frame silence tuples (profiles/r03_realtext_timeline_before.txt), a latency chain of ~100 round trips
+// per wavefront.  Here the wave first loads, for every tuple i, the cells of column phoneme_i over the frames
+// [start_i - K, end_i + K) -- a flat list of cells over all tuples, 64 lanes x 8 independent loads at a time, four or five
+// round trips for the whole utterance -- converts them once (exp_cr, all lanes busy) and leaves the float32
+// probabilities in LDS; the passes, the segment means and the confidences then run tuple-per-lane at LDS speed.  A
+// probe outside a tuple's staged window (an extension running further than K frames) falls back to the global read, so
+// the result does not depend on K.  Arithmetic and order of operations are those of k_postprocess / k_conf.
+// =====================================================================================================================
+struct PostConfArgs {
+    const float *logp;
+    float *row_stats;
+    int64_t strideB, strideT;
+    int32_t B, Tmax, C;
+    const int32_t *S_len;   // do_post
+    bfa_segment *segs;
+    int32_t seg_cap;
+    int32_t *seg_count;
+    int32_t do_post, extend, do_conf;
+    double th1, th2;
+    const int32_t *T_rows;  // do_conf (nullptr: Tmax)
+    float *conf;
+    int32_t *status;
+    int32_t cap_cells;      // floats of LDS for the staged probabilities
+};
+
+#ifndef BFA_STAGE_K
+#define BFA_STAGE_K 4
+#endif
+constexpr int STAGE_K = BFA_STAGE_K; // frames staged on either side of a tuple (probes beyond fall back to memory)
+
+template <bool RAW>
+struct StagedProb {
+    const LpView<RAW> &lp;
+    const float *sp;
+    const int32_t *off, *wlo, *whi;
+    // exp(log_prob[f, ph]) of tuple i's column: from the staged window, else from memory
+    __device__ __forceinline__ float at(int i, int f, int ph) const
+    {
+        const int lo = wlo[i];
+        if (f >= lo && f < whi[i]) return sp[off[i] + (f - lo)];
+        return exp_cr(lp.at(f, ph));
+    }
+};
+
+template <bool RAW>
+__global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    // [seg_cap] doubles | [seg_cap] tuples | 3 x [seg_cap] ints | [cap_cells] floats
+    double *smean = (double *)dyn_lds;
+    bfa_segment *st = (bfa_segment *)(dyn_lds + (size_t)a.seg_cap * 8);
+    int32_t *off = (int32_t *)(dyn_lds + (size_t)a.seg_cap * (8 + sizeof(bfa_segment)));
+    int32_t *wlo = off + a.seg_cap, *whi = wlo + a.seg_cap;
+    float *sp = (float *)(whi + a.seg_cap);
+    const int lane = threadIdx.x & 63;
+    const double th1 = a.th1, th2 = a.th2;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        bfa_segment *sg = a.segs + (int64_t)b * a.seg_cap;
+        const LpView<RAW> lp{a.logp + (int64_t)b * a.strideB, a.strideT,
+                             RAW ? a.row_stats + 2 * (int64_t)b * a.Tmax : nullptr, a.C};
+        int n = a.seg_count[b];
+        if (n > a.seg_cap) n = a.seg_cap;
+        int m = n;
+        post_sync(); // the previous utterance's readers of the LDS arrays are done
+        if (a.do_post) {
+            // ---- ensure_target_coverage (default): drop idx == -1 or idx >= S (core.py:488-513)
+            const int S = a.S_len[b];
+            m = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                bfa_segment g;
+                bool keep = false;
+                if (i < n) { g = sg[i]; keep = (g.target_idx != -1 && g.target_idx < S); }
+                const unsigned long long km = __ballot(keep);
+                if (keep) st[m + __builtin_popcountll(km & ((1ull << lane) - 1ull))] = g;
+                m += __builtin_popcountll(km);
+            }
+            post_sync();
+            // stable sort by start (core.py:660); assort output is already ordered, so this is a check
+            int unsorted = 0;
+            for (int i = lane; i + 1 < m; i += 64) if (st[i].start > st[i + 1].start) unsorted = 1;
+            if (__any(unsorted)) {
+                if (lane == 0) {
+                    for (int i = 1; i < m; ++i) {
+                        const bfa_segment key = st[i];
+                        int j = i - 1;
+                        while (j >= 0 && st[j].start > key.start) { st[j + 1] = st[j]; --j; }
+                        st[j + 1] = key;
+                    }
+                }
+                post_sync();
+            }
+        } else {
+            for (int i = lane; i < m; i += 64) st[i] = sg[i];
+            post_sync();
+        }
+        const int Tpad = a.Tmax;                      // the soft-boundary stage works on the padded rows (core.py:705)
+        int Tc = a.T_rows ? a.T_rows[b] : a.Tmax;     // the confidence pass on log_probs.shape[0] as the caller passes it
+        if (Tc > a.Tmax) Tc = a.Tmax;
+        const bool staging = (a.do_post && a.extend) || a.do_conf;
+        // ---- the windows: [start - K, end + K) clipped to the rows, K = 0 without the extension passes
+        int total = 0;
+        if (staging) {
+            const int K = (a.do_post && a.extend) ? STAGE_K : 0;
+            for (int base = 0; base < m; base += 64) {
+                const int i = base + lane;
+                int len = 0, lo = 0;
+                if (i < m) {
+                    const bfa_segment g = st[i];
+                    const int s0 = max(0, g.start), e0 = min(a.Tmax, g.end);
+                    if (g.phoneme >= 0 && g.phoneme < a.C && s0 < a.Tmax) {
+                        lo = max(0, s0 - K);
+                        const int hi = min(a.Tmax, max(e0, s0 + 1) + K);
+                        len = hi - lo;
+                    }
+                }
+                // exclusive prefix sum of len over the 64 lanes
+                int incl = len;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+                if (i < m) { off[i] = total + incl - len; wlo[i] = lo; whi[i] = lo + len; }
+                total += __shfl(incl, 63);
+            }
+            if (total > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
+                for (int i = lane; i < m; i += 64) whi[i] = wlo[i];
+                total = 0;
+            }
+            post_sync();
+            // ---- stage: cell c belongs to the tuple i with off[i] <= c < off[i] + len_i (binary search), frame wlo[i] + (c - off[i])
+            constexpr int U = 8;
+            for (int c0 = 0; c0 < total; c0 += 64 * U) {
+                float x[U];
+                float2 ms[U];
+                int cell[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = min(c0 + u * 64 + lane, total - 1);
+                    int lo_i = 0, hi_i = m - 1; // last tuple with off <= c (empty windows share their successor's offset)
+                    while (lo_i < hi_i) { const int mid = (lo_i + hi_i + 1) >> 1; if (off[mid] <= c) lo_i = mid; else hi_i = mid - 1; }
+                    const int f = wlo[lo_i] + (c - off[lo_i]);
+                    const int ph = st[lo_i].phoneme;
+                    cell[u] = c;
+                    x[u] = lp.lp[(int64_t)f * lp.ld + ph];
+                    if (RAW) ms[u] = *(const float2 *)(lp.st + 2 * (int64_t)f);
+                    else ms[u] = make_float2((float)f, (float)ph); // (unused)
+                    if (RAW && (ms[u].x != ms[u].x || ms[u].y != ms[u].y)) ms[u] = row_stats_on_demand(lp.lp + (int64_t)f * lp.ld, lp.C, lp.st + 2 * (int64_t)f);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float v = RAW ? ((x[u] - ms[u].x) - ms[u].y) : x[u];
+                    if (c0 + u * 64 + lane < total) sp[cell[u]] = exp_cr(v);
+                }
+            }
+            post_sync();
+        }
+        const StagedProb<RAW> pr{lp, sp, off, wlo, whi};
+        if (a.do_post && a.extend) {
+            // ---- segment means (core.py:709-714): float32 mean, accumulated in double, rounded once
+            for (int i = lane; i < m; i += 64) {
+                const bfa_segment g = st[i];
+                double mean = 0.001;
+                if (g.start < Tpad && g.phoneme < a.C && g.start < g.end) {
+                    const int ee = g.end > Tpad ? Tpad : g.end;
+                    double acc = 0.0;
+                    for (int f = g.start; f < ee; ++f) acc += (double)pr.at(i, f, g.phoneme);
+                    mean = (double)(float)(acc / (double)(ee - g.start));
+                }
+                smean[i] = mean;
+            }
+            post_sync();
+            // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
+            for (int pass = 1; pass <= 4; ++pass) {
+                for (int i = lane; i < m; i += 64) {
+                    const int ph = st[i].phoneme, s = st[i].start, e = st[i].end;
+                    if (s >= Tpad || ph >= a.C) continue; // :719,:740,:760,:784
+                    const int d = e - s;
+                    if (pass == 1) { // :717-735
+                        int min_start = (int)((double)s - (double)d * 10.0);
+                        if (min_start < 0) min_start = 0;
+                        if (i > 0) { int v = st[i - 1].end + 10; if (v > s) v = s; if (v > min_start) min_start = v; }
+                        double thr = smean[i] * th1; if (thr > th1) thr = th1;
+                        int ns = s;
+                        for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= thr) ns = f; else break; }
+                        st[i].start = ns;
+                    } else if (pass == 2) { // :738-755
+                        int max_end = (int)((double)e + (double)d * 10.0);
+                        if (max_end > Tpad) max_end = Tpad;
+                        if (i + 1 < m) { int v = st[i + 1].start - 10; if (v > e) v = e; if (v < max_end) max_end = v; }
+                        double thr = smean[i] * th1; if (thr > th1) thr = th1;
+                        int ne = e;
+                        for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= thr) ne = f + 1; else break; }
+                        st[i].end = ne;
+                    } else if (pass == 3) { // :758-778
+                        int min_start = 0;
+                        if (i > 0) min_start = st[i - 1].end;
+                        if (s <= min_start) continue;
+                        int ns = s;
+                        for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= th2) ns = f; else break; }
+                        st[i].start = ns;
+                    } else { // :782-805
+                        int max_end = (int)((double)e + (double)d * 10.0);
+                        if (max_end > Tpad) max_end = Tpad;
+                        if (i + 1 < m) { const int v = st[i + 1].start; if (v < max_end) max_end = v; }
+                        int ne = e;
+                        for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= th2) ne = f + 1; else break; }
+                        st[i].end = ne;
+                    }
+                }
+                post_sync();
+            }
+        }
+        if (a.do_post) {
+            for (int i = lane; i < m; i += 64) sg[i] = st[i];
+            if (lane == 0) a.seg_count[b] = m;
+        }
+        if (a.do_conf) {
+            // ---- _calculate_confidences (utils.py:70-113) on the tuples as they are now
+            float *cf = a.conf + (int64_t)b * a.seg_cap;
+            int bad = 0;
+            // does any tuple read a cell that an earlier tuple has written through its 0-dim view?
+            int alias = 0;
+            for (int i = lane; i < m; i += 64) {
+                const int ph = st[i].phoneme;
+                const int s = max(0, st[i].start), e = min(Tc, st[i].end);
+                for (int k = 0; k < i; ++k) {
+                    if (st[k].phoneme != ph) continue;
+                    const int sk = max(0, st[k].start);
+                    if (sk == s || (sk >= s && sk < e)) { alias = 1; break; }
+                }
+            }
+            alias = __any(alias);
+            if (!alias) {
+                for (int i = lane; i < m; i += 64) {
+                    const int ph = st[i].phoneme;
+                    const int s = max(0, st[i].start), e = min(Tc, st[i].end); // :86-87
+                    if (s >= Tc || ph < 0 || ph >= a.C) { bad = 1; cf[i] = 0.0f; continue; } // IndexError at :89
+                    float c = pr.at(i, s, ph);
+                    if (s < e) {
+                        const float half = c / 2.0f; // :95 (a fresh tensor: stays constant)
+                        int good = 1;
+                        float mx = 0.0f;
+                        for (int f = s + 1; f < e; ++f) {
+                            const float v = pr.at(i, f, ph);
+                            mx = (f == s + 1) ? v : __builtin_fmaxf(mx, v);
+                            if (v > half || v > 0.1f) { c = c + v; good++; } // :101-103
+                        }
+                        if (good > 1) {
+                            c = c / (float)good; // :105 -- this also lands in probs[start, ph] ...
+                            const float m2 = __builtin_fmaxf(c, mx); // ... so :107 sees the mean at `start`
+                            if (c < m2 / 2.0f) c = m2;
+                        }
+                    }
+                    cf[i] = c;
+                }
+            } else if ((size_t)m * 5 <= (size_t)a.cap_cells * 4) {
+                // exact serial replay with the write-through cells (rare: overlapping tuples of one phoneme); the staged
+                // probabilities are not needed any more: their LDS holds the replay's cells
+                post_sync();
+                float *mval = sp;
+                uint8_t *mflag = (uint8_t *)(sp + m);
+                for (int i = lane; i < m; i += 64) mflag[i] = 0;
+                post_sync();
+                if (lane == 0) {
+                    auto prob = [&](int f, int ph, int upto) -> float {
+                        for (int k = upto; k >= 0; --k)
+                            if (mflag[k] && st[k].phoneme == ph && max(0, st[k].start) == f) return mval[k];
+                        return exp_cr(lp.at(f, ph));
+                    };
+                    for (int i = 0; i < m; ++i) {
+                        const int ph = st[i].phoneme;
+                        const int s = max(0, st[i].start), e = min(Tc, st[i].end);
+                        if (s >= Tc || ph < 0 || ph >= a.C) { bad = 1; cf[i] = 0.0f; continue; }
+                        float c = prob(s, ph, i - 1);
+                        if (s < e) {
+                            const float half = c / 2.0f;
+                            int good = 1;
+                            for (int f = s + 1; f < e; ++f) {
+                                const float v = prob(f, ph, i);
+                                if (v > half || v > 0.1f) { c = c + v; good++; mval[i] = c; mflag[i] = 1; }
+                            }
+                            if (good > 1) {
+                                c = c / (float)good; mval[i] = c; mflag[i] = 1;
+                                float mx = prob(s, ph, i);
+                                for (int f = s + 1; f < e; ++f) mx = __builtin_fmaxf(mx, prob(f, ph, i));
+                                if (c < mx / 2.0f) c = mx;
+                            }
+                        }
+                        cf[i] = c;
+                    }
+                }
+                post_sync();
+            } else {
+                bad = 1;
+            }
+            bad = __any(bad);
+            if (lane == 0 && a.status) a.status[b] = bad ? BFA_ITEM_BAD_TOKEN : BFA_ITEM_OK;
+        }
+    }
+}
+
+// bytes of dynamic LDS k_postconf needs for these shapes, or 0 when it does not fit (the caller then takes the
+// tuple-per-lane kernels): tuples of one alignment are disjoint runs, so Tmax + 2 K seg_cap cells hold every window
+static size_t postconf_lds(int Tmax, int seg_cap, int *cap_cells)
+{
+    const size_t cells = (size_t)Tmax + 2 * (size_t)bfa::STAGE_K * (size_t)seg_cap + 64;
+    const size_t bytes = (size_t)seg_cap * (8 + sizeof(bfa_segment) + 12) + cells * 4;
+    if (bytes > 60 * 1024) return 0;
+    *cap_cells = (int)cells;
+    return bytes;
+}
+
 } // namespace bfa
 
 extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
@@ -166,5 +483,29 @@ extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64
     }
     if (row_stats) hipLaunchKernelGGL(k_postprocess<true>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL(k_postprocess<false>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
+// postprocess and / or confidences of a batch through k_postconf; returns -1 when the shapes do not fit its LDS staging
+extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                                   const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int do_post,
+                                   int extend, double th1, double th2, int do_conf, const int32_t *T_rows, float *conf,
+                                   int32_t *status, void *stream_)
+{
+    using namespace bfa;
+    int cap_cells = 0;
+    const size_t lds = postconf_lds(Tmax, seg_cap, &cap_cells);
+    if (lds == 0) return -1;
+    PostConfArgs a;
+    a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C;
+    a.S_len = S_len; a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.do_post = do_post; a.extend = extend;
+    a.do_conf = do_conf; a.th1 = th1; a.th2 = th2; a.T_rows = T_rows; a.conf = conf; a.status = status; a.cap_cells = cap_cells;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_postconf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_postconf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int grid = B < 65536 ? B : 65536;
+    if (row_stats) hipLaunchKernelGGL(k_postconf<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(k_postconf<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
