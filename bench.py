@@ -483,16 +483,23 @@ def _shard_digest(idx):
     return int.from_bytes(hashlib.sha256(np.ascontiguousarray(idx, np.int64).tobytes()).digest()[:8], "little") >> 1
 
 
-def c4_plan(n_total, world, seed, chunk):
-    """Host-side plan, identical on every rank: lengths, the LPT partition (sharding.shard_utterances on T*(4S+1)),
-    and per shard the length-sorted sub-batches ("chunks") one bfa_align_batch call takes."""
+def c4_plan(n_total, world, seed, chunk, halves=1):
+    """Host-side plan, identical on every rank: lengths, the LPT partition (sharding.shard_utterances on the DP work
+    T*(4S+1); a rank's predicted time max(chain, work / machine rate) is reported beside the measured one), and per shard
+    `halves` sub-shards that are
+    aligned side by side (every halves-th utterance of the length-sorted shard: the same length mix in each), each cut
+    into the length-sorted sub-batches ("chunks") one bfa_align_batch call takes.  plans[rank][half] = list of chunks."""
     from bournemouth_forced_aligner_amd.sharding import shard_utterances, utterance_cost
     T, S = c4_lengths(n_total, seed)
     shards = shard_utterances(T, S, world)
     plans = []
     for s in shards:
         order = s[np.argsort(-T[s], kind="stable")]  # longest first: similar lengths share a call (less padding,
-        plans.append([order[i:i + chunk] for i in range(0, len(order), chunk)])  # fewer K1 classes per call)
+        subs = []                                    # fewer K1 classes per call)
+        for hf in range(halves):
+            o = order[hf::halves]
+            subs.append([o[i:i + chunk] for i in range(0, len(o), chunk)])
+        plans.append(subs)
     cost = utterance_cost(T, S)
     loads = np.array([cost[s].sum() for s in shards], np.float64)
     return T, S, shards, plans, loads
@@ -502,7 +509,8 @@ def c4_main(args, rk):
     dev, rank, world, dist = rk.dev, rk.rank, rk.world, rk.dist
     C, seed, n_total = args.classes, args.seed, args.global_batch
     blank = C - 1
-    T, S, shards, plans, loads = c4_plan(n_total, world, seed, args.chunk)
+    halves = max(1, args.halves)
+    T, S, shards, plans, loads = c4_plan(n_total, world, seed, args.chunk, halves)
     mine = shards[rank]
     # every rank must have computed the same partition
     digest = _shard_digest(np.concatenate([np.asarray([len(x) for x in shards], np.int64)] + list(shards)))
@@ -512,7 +520,7 @@ def c4_main(args, rk):
     allidx = np.sort(np.concatenate(shards))
     assert np.array_equal(allidx, np.arange(n_total)), "the shards are not a partition of the batch"
 
-    from bournemouth_forced_aligner_amd.sharding import gather_results
+    from bournemouth_forced_aligner_amd.sharding import gather_results, predict_rank_ms
     cap = int(S.max()) + 2
     if rk.dry:
         # no GPU work: exercise launch, partition agreement and the gather plumbing with fabricated records
@@ -542,7 +550,9 @@ def c4_main(args, rk):
     # ---- synthesis: each rank makes only its own utterances (sub-batches of <= 512 to bound the temporaries)
     t_s0 = time.perf_counter()
     chunks = []
-    for ch in plans[rank]:
+    for hf, ch in [(hf, ch) for hf in range(halves) for ch in plans[rank][hf]]:
+        if len(ch) == 0:
+            continue
         Tp, Sp = int(T[ch].max()), int(S[ch].max())
         lps, tks = [], []
         for i in range(0, len(ch), 512):
@@ -556,7 +566,7 @@ def c4_main(args, rk):
         Td = torch.from_numpy(T[ch].astype(np.int32)).to(dev)
         Sd = torch.from_numpy(S[ch].astype(np.int32)).to(dev)
         hint = vd.class_mask_hint(T[ch], S[ch], has_sil=False, n_classes=C)
-        chunks.append(dict(idx=ch, lp=lp, tk=tk, Td=Td, Sd=Sd, hint=hint, csum=input_checksum(lp, T[ch])))
+        chunks.append(dict(idx=ch, lp=lp, tk=tk, Td=Td, Sd=Sd, hint=hint, csum=input_checksum(lp, T[ch]), half=hf))
     torch.cuda.synchronize()
     synth_s = time.perf_counter() - t_s0
     my_frames = int(T[mine].sum())
@@ -565,13 +575,16 @@ def c4_main(args, rk):
     # --inflight k: k steps in flight, each on its own stream with its own decoder (workspace) and library handle (aux
     # streams).  A rank's shard of a sharded batch is bound by the chain of its longest utterance, not by the machine;
     # a service that aligns a stream of such batches overlaps them.  `value` stays frames / wall time.
+    # --halves h (default 2): the rank's shard as h sub-shards side by side, each with its own stream, decoder and library
+    # handle: the chains of one sub-shard's long utterances run beside the short work of the other.
     nfl = max(1, args.inflight or 1)
+    nlanes = nfl * halves
     aus = [au]
-    for k in range(1, nfl):
+    for k in range(1, nlanes):
         a2 = AlignmentUtils(blank_id=blank, silence_id=0)
         a2.viterbi_decoder.handle_slot = k
         aus.append(a2)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)] if nfl > 1 else None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nlanes)] if nlanes > 1 else None
     step_no = [0]
 
     def step():
@@ -580,9 +593,13 @@ def c4_main(args, rk):
         if streams is None:
             return [au.decode_alignments_device(c["lp"], c["tk"], c["Td"], c["Sd"], class_mask=c["hint"], seg_cap=cap)
                     for c in chunks]
-        with torch.cuda.stream(streams[k]):
-            return [aus[k].decode_alignments_device(c["lp"], c["tk"], c["Td"], c["Sd"], class_mask=c["hint"], seg_cap=cap)
-                    for c in chunks]
+        out = []
+        for c in chunks:
+            lane = k * halves + c["half"]
+            with torch.cuda.stream(streams[lane]):
+                out.append(aus[lane].decode_alignments_device(c["lp"], c["tk"], c["Td"], c["Sd"], class_mask=c["hint"],
+                                                              seg_cap=cap))
+        return out
 
     for _ in range(max(1, args.warmup)):
         res = step()
@@ -646,9 +663,13 @@ def c4_main(args, rk):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4: global batch={n_total} mixed-length T~U[200,3000] S=T//25 ph66 (C={C}), seed {seed}, "
                                    f"reference-default flags; {nfl} step(s) in flight; LPT-sharded over {world} rank(s), "
-                                   f"{len(chunks)} length-sorted calls of <= {args.chunk} utterances per rank",
-                       "global_batch": n_total, "parallelism": f"utterance-sharded x{world} (LPT on T*(4S+1)), "
-                                                               f"no data-path collective, final gather of records"},
+                                   f"per rank {halves} sub-shard(s) side by side in {len(chunks)} length-sorted calls of "
+                                   f"<= {args.chunk} utterances",
+                       "global_batch": n_total, "sub_shards_in_flight": halves,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                       "parallelism": f"utterance-sharded x{world} (LPT on T*(4S+1)), "
+                                      f"no data-path collective, final gather of records"},
+            "predicted_rank_ms": [predict_rank_ms(T[s], S[s]) for s in shards],
             "frames_per_step": total_frames,
             "value_with_gather": total_frames / (step_s + gather_ms * 1e-3),
             "gather_ms": gather_ms,
@@ -958,6 +979,8 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: ONE unsorted mixed-length call T~U{200..3000}, S=T//25")
     ap.add_argument("--global-batch", type=int, default=32768, help="c4: utterances over all ranks")
+    ap.add_argument("--halves", type=int, default=1,
+                    help="c4: sub-shards of a rank's shard aligned side by side (own stream / decoder / library handle each)")
     ap.add_argument("--chunk", type=int, default=16384, help="c4: utterances per bfa_align_batch call (one call per rank when the shard is smaller)")
     ap.add_argument("--seed", type=int, default=1004, help="c4: generator seed")
     ap.add_argument("--parity-sample", type=int, default=None,

@@ -17,8 +17,31 @@ def utterance_cost(T, S):
     return T * (4 * S + 1)
 
 
+# What one rank's shard costs (MI355X, measured in round 3 on BASELINE config 4, profiles/r03_c4*.json): a call is bound
+# either by the serial chain of its longest utterance (the forward recurrence of forced_alignment.py:608-653 is serial in
+# t: ~0.42 us per frame beside the rest of the call, plus planning / walk) or by the machine (frames per second of the
+# whole call), whichever is longer.
+CHAIN_MS_PER_FRAME = 0.42e-3
+CHAIN_MS_FIXED = 0.10
+MACHINE_FRAMES_PER_MS = 7.0e6
+
+
+def predict_rank_ms(T_lens, S_lens):
+    """{"chain_ms", "work_ms", "predicted_ms"} of one rank's shard: max(chain of the longest utterance, frames / machine
+    rate).  A model for reporting and for the partition below, not a guarantee."""
+    T = np.asarray(T_lens, np.int64)
+    if T.size == 0:
+        return {"chain_ms": 0.0, "work_ms": 0.0, "predicted_ms": 0.0}
+    chain = CHAIN_MS_FIXED + CHAIN_MS_PER_FRAME * float(T.max())
+    work = float(T.sum()) / MACHINE_FRAMES_PER_MS
+    return {"chain_ms": chain, "work_ms": work, "predicted_ms": max(chain, work)}
+
+
 def shard_utterances(T_lens, S_lens, world_size):
-    """Longest-processing-time-first assignment of utterances to ranks.
+    """Longest-processing-time-first assignment of utterances to ranks on the DP work (frames x CTC states).
+    A rank's time is max(chain of its longest utterance, its work / machine rate) (predict_rank_ms): whatever the
+    partition, SOME rank holds the batch's longest utterance and the chains of one rank run side by side, so the maximum
+    over ranks is max(longest chain of the batch, largest work share) -- balancing the work is all a partition can do.
     Returns list[world_size] of index arrays (sorted ascending inside each shard)."""
     cost = utterance_cost(T_lens, S_lens)
     order = np.argsort(-cost, kind="stable")

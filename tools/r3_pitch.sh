@@ -7,7 +7,7 @@ for rep in 1 2 3; do
   for p in 0 68 72 80; do
     python bench.py --steps 20 --warmup 5 --no-cpu --row-pitch $p --kernel-leg-steps 100 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); r=d['roofline']
 print('pitch', d['config']['row_pitch_floats'], 'step_ms %.4f' % d['ms_per_step'], 'kernel_ms %.4f' % r['kernel_ms'], 'median %.4f' % r['kernel_ms_stats']['median'], 'leg_step_ms %.4f' % r['kernel_leg_ms_per_step'])"
   done
 done | tee $OUT/pitch_ab.txt

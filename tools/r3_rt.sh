@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-rt}
 OUT=$ROOT/gpurun_out/r3; mkdir -p $OUT; cd $ROOT
-ms() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'ms/step %.4f' % d['ms_per_step'], 'parity', (d.get('parity') or {}).get('mismatching_utterances'), (d.get('parity') or {}).get('confidence_beyond_1e-4'), 'segmented', d.get('segmented_utterances'))"; }
+ms() { python -c "import json,sys; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$1', 'ms/step %.4f' % d['ms_per_step'], 'parity', (d.get('parity') or {}).get('mismatching_utterances'), (d.get('parity') or {}).get('confidence_beyond_1e-4'), 'segmented', d.get('segmented_utterances'))"; }
 python bench.py --config realtext --steps 20 --warmup 5 2> $OUT/rt_$TAG.err | tee $OUT/realtext_$TAG.json | ms "realtext inflight1"
 tail -3 $OUT/rt_$TAG.err
 python bench.py --config realtext --steps 20 --warmup 5 --parity-sample 0 --inflight 2 2>/dev/null | ms "realtext inflight2"
