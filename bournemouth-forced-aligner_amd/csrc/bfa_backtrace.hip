@@ -538,6 +538,8 @@ __device__ __forceinline__ bool k2_selected(int sel, const Item &it)
     // a window item whose window kernel ended above the sentinel (the others are rerun with the full layout: win < 0)
     const bool window_done = it.kind == ITEM_DP && it.win > 0 && it.final_state != FINAL_NOT_COMPUTED;
     if (sel == K2_WIN) return window_done;
+    if ((sel & 0xff) == K2_NARROW) // the merged narrow kernel's items: its window classes and the full-layout classes of its mask
+        return window_done || (plain_full && it.L <= 256 && (((unsigned)sel >> 8) & r_class_bit(r_class_for_L(it.L))) != 0u);
     if (sel == K2_REST_NOWIN) return !plain_full && !window_done;
     if (sel == K2_REST) return !plain_full;
     if (!plain_full) return false;

@@ -100,6 +100,7 @@ struct AlignArgs {
     int32_t k2_windows;     // launcher: the window items are walked behind the window kernels on their stream (K2_WIN)
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
+constexpr int K2_NARROW = 64; // | (class bits of the merged narrow full-layout classes << 8): K2_WIN + those classes (k_dp4w_any)
 
 struct ConfArgs {
     const float *logp;
