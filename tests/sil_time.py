@@ -55,3 +55,10 @@ gs, gc = res.segs[:64].cpu().numpy(), res.seg_count[:64].cpu().numpy()
 mism = sum(int(gc[b] != exp["seg_count"][b] or not (gs[b, :gc[b]] == exp["seg"][b, :gc[b]]).all()) for b in range(64))
 print(f"B={NB * rep} T={T} S={S} with SIL, {NFL} in flight: {ms:.3f} ms per step = {NB * rep * T / ms / 1e6:.2f} G frames/s; "
       f"segmented utterances {int((md == 1).sum())}/{len(md)}; parity sample mismatches {mism}/64")
+import json  # noqa: E402
+print(json.dumps({"workload": f"silence-anchored mode, phoneme head from log-probs: batch={NB * rep} T={T} S={S}, SIL at 1/12 of the "
+                              f"targets, planted 12-40-frame silences; {NFL} step(s) in flight", "ms_per_step": ms,
+                  "frames_per_s": NB * rep * T / (ms * 1e-3), "segmented_utterances": int((md == 1).sum()), "of": int(len(md)),
+                  "algorithmic_bytes_per_frame": 4 * C + 4 * C + (4 * S + 1 + 3) // 4 + 8,
+                  "hbm_frac": NB * rep * T * (4 * C + 4 * C + (4 * S + 1 + 3) // 4 + 8) / (ms * 1e-3) / 1e9 / 8000.0,
+                  "parity_sample": {"utterances": 64, "mismatching_utterances": mism}}))
