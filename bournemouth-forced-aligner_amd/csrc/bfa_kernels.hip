@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "bfa_assort.hpp"
+#include "bfa_plan.inc"
 #include "bfa_softmax.hpp"
 
 #pragma clang fp contract(off)
@@ -30,10 +31,8 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // =================================================================================================
-// k_plan : sixteen lanes per utterance scan its tokens (coalesced, 16 at a time), lane 0 of the group plans
+// k_plan : sixteen lanes per utterance (bfa_plan.inc)
 // =================================================================================================
-__device__ __forceinline__ int band_standard(int L) { return (L > 60) ? ((L / 4 > 20) ? L / 4 : 20) : 0; } // :190, :976
-
 __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,105 +46,7 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
         if (a.p.win_mask & 0x80000000u) { for (int k = 1; k < 16; ++k) a.counters[k] = 0; }
     }
     if (b >= a.B) return; // whole 16-lane groups
-    const DevParams &p = a.p;
-    const int Traw = a.T_len ? a.T_len[b] : a.Tmax;
-    int T = Traw;
-    if (T > a.Tmax) T = a.Tmax; // python slicing clamps (forced_alignment.py:887)
-    if (T < 0) T = 0;
-    int S = a.S_len[b];
-    if (S > a.Smax) S = a.Smax;
-    if (S < 0) S = 0;
-
-    uint32_t m[MASK_WORDS];
-#pragma unroll
-    for (int w = 0; w < MASK_WORDS; ++w) m[w] = 0u;
-    int flags = 0; // bit 0: bad token, bit 1: the silence id occurs
-    const int32_t *tk = a.tokens + (int64_t)b * a.Smax;
-    for (int j = sub; j < S; j += 16) {
-        const int t = tk[j];
-        if (t < 0 || t >= a.C) { flags |= 1; continue; }
-        if (t == p.sil) flags |= 2;
-        if (t == p.blank) continue; // :45
-#pragma unroll
-        for (int w = 0; w < MASK_WORDS; ++w) m[w] |= ((t >> 5) == w) ? (1u << (t & 31)) : 0u;
-    }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        flags |= __shfl_xor(flags, off, 16);
-#pragma unroll
-        for (int w = 0; w < MASK_WORDS; ++w) m[w] |= __shfl_xor(m[w], off, 16);
-    }
-    if (sub != 0) return;
-    a.uT[b] = T;
-    a.uS[b] = S;
-    int status = (flags & 1) ? BFA_ITEM_BAD_TOKEN : BFA_ITEM_OK;
-    const bool has_sil = (flags & 2) != 0;
-#pragma unroll
-    for (int w = 0; w < MASK_WORDS; ++w) a.umask[(int64_t)b * MASK_WORDS + w] = m[w];
-
-    Item it;
-    it.kind = ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = T; it.tok0 = 0; it.nt = S; it.stride = 0; it.L = 0;
-    it.bw = 0; it.out0 = 0; it.nout = T; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.split = 0;
-    it.bp_off = (int64_t)b * a.bp_per_utt;
-    int mode = BFA_MODE_EMPTY;
-
-    if (status != BFA_ITEM_OK) {
-        it.kind = ITEM_FILL_BLANK;
-    } else if (S == 0 && !p.simple) { // :894-897 (and :112-118); decode_alignments_simple has no such shortcut (:951-985)
-        it.kind = ITEM_FILL_BLANK;
-        mode = BFA_MODE_EMPTY;
-    } else if (p.simple) { // forced_alignment.py:963-976, lengths are 0-dim int64 tensors -> float32 compares
-        int stride = 4;
-        if ((float)(stride * S + 1) > (float)Traw * 0.9f) stride = 3;
-        if ((float)(stride * S + 1) > (float)Traw * 0.8f) stride = 2;
-        it.stride = stride;
-        it.L = stride * S + 1;
-        it.bw = band_standard(it.L);
-        mode = BFA_MODE_STANDARD;
-        if (T < 1) { status = BFA_ITEM_TOO_SHORT; it.kind = ITEM_FILL_BLANK; }
-        else it.kind = ITEM_DP;
-    } else {
-        const bool no_sil_hint = (p.class_mask & BFA_HINT_NO_SILENCE_TARGETS) != 0;
-        const bool seg_candidate = (p.anchors > 0 && p.sil >= 0 && has_sil && !no_sil_hint);
-        if (p.anchors > 0 && p.sil >= 0 && has_sil && no_sil_hint) status = BFA_ITEM_BAD_HINT;
-        // standard mode (also the fallback of the segmented attempt)
-        int stride = 4; // :153-157
-        if (stride * S + 1 > T) stride = 3;
-        if (stride * S + 1 > T) stride = 2;
-        if (stride * S + 1 > T) stride = 1;
-        const int L = stride * S + 1;
-        it.stride = stride;
-        it.L = L;
-        bool fallback_short = false;
-        if (L > T) {
-            if (T < S) { // :161-165 -- but the segmented attempt comes first (:131-141): only its failure is the error
-                it.kind = ITEM_FILL_BLANK;
-                if (seg_candidate && status == BFA_ITEM_OK) { fallback_short = true; mode = BFA_FALLBACK_TOO_SHORT; }
-                else status = BFA_ITEM_TOO_SHORT;
-            } else { it.kind = ITEM_FILL_PROP; mode = BFA_MODE_PROPORTIONAL; }      // :166-176
-        } else {
-            it.kind = ITEM_DP;
-            it.bw = band_standard(L);
-            mode = BFA_MODE_STANDARD;
-            // band narrow enough, and the utterance short enough in frames and tokens, for the window?
-            const int rw = (S <= p.win_max_tokens) ? win_class_for(L, it.bw, T, p.win_max_frames) : 0;
-            if (rw > 0 && ((p.win_mask >> (rw - 1)) & 1u)) it.win = rw;
-        }
-        (void)fallback_short;
-        if (a.ucand) a.ucand[b] = (seg_candidate && status == BFA_ITEM_OK) ? 1 : 0;
-        if (seg_candidate && status == BFA_ITEM_OK) { // k_plan_segmented decides (it may keep this fallback)
-            mode = -1 - mode;
-            a.cand[atomicAdd(&a.counters[1], 1)] = b;
-        }
-    }
-    if (it.kind == ITEM_DP && it.L > BIG_MAX_L) { // beyond the workgroup-wide kernel as well
-        status = BFA_ITEM_TOO_LARGE;
-        it.kind = ITEM_FILL_BLANK;
-    }
-    a.items[b] = it;
-    a.status[b] = status;
-    a.umode[b] = mode;
-    a.seg_count[b] = 0;
+    plan_utterance(a, b, sub);
 }
 
 // =================================================================================================
@@ -311,6 +212,8 @@ extern "C" void bfa_launch_dp_big_nk8(const bfa::AlignArgs *args, int grid, hipS
 extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream, int wide);
 extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, int fused, int grid, hipStream_t stream, int wide);
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
+extern "C" void bfa_k1_one_nk2(const bfa::AlignArgs *a, int RW, hipStream_t s);
+extern "C" void bfa_k1_one_nk5(const bfa::AlignArgs *a, int RW, hipStream_t s);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
                                 void **aux_streams, void **aux_events, void *fork_event, int naux)
@@ -348,6 +251,20 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     a.k2_sel = K2_ALL;
     a.k2_fused_rle = fused_k2 ? 1 : 0;
     a.k2_per_class = per_class_k2 ? 1 : 0;
+    // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
+    // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
+    {
+        static const int one_max = [] { const char *e = getenv("BFA_ONE_MAX_BATCH"); return e ? atoi(e) : 1024; }(); // (0 switches it off)
+        const unsigned hw = (p.class_mask >> 8) & 0xffu;
+        const int rw1 = (hw == 1u) ? 1 : (hw == 2u) ? 2 : (hw == 4u) ? 3 : 0;
+        if (fused_k2 && rw1 > 0 && (p.class_mask & 0x7fu) == 0 && (wmask >> (rw1 - 1) & 1u) && a.B <= one_max && Lmax <= 256 &&
+            a.frame_ph && a.frame_idx) {
+            if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+            if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);
+            if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
+            return (int)hipGetLastError();
+        }
+    }
     if (seg_possible) (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
     else a.p.win_mask |= 0x80000000u; // k_plan zeroes the counters (see there)
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
