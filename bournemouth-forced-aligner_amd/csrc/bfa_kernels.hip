@@ -240,6 +240,10 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     }
     // (the window result is exact because emissions are <= 0; a floor above log(1) = 0 would break that argument)
     if (!(p.min_logp <= 0.0f)) wmask = 0;
+    // Silence-anchored mode: no sliding window.  Only the few utterances whose segmented attempt fails would use it, and
+    // the window consumers in the mode's merged K1 kernel cost every PIECE 30 spilled VGPRs (one 256-byte scratch store per
+    // item and spilled register: 0.29 GB of DRAM writes per 4096-utterance launch; realtext 1.54 -> 1.49 ms per step).
+    if (seg_possible) wmask = 0;
     a.p.win_mask = wmask;
     mask |= wmask << 8;
     // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
@@ -273,8 +277,8 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // one kernel per class; with more than one class to launch they run side by side on the auxiliary streams
     // (silence-anchored mode on the two head widths: the narrow classes are one launch on the caller's stream, bfa_dp3.inc)
     const bool merged_narrow = mode == 1 && (a.C == 67 || a.C == 17);
-    const unsigned kmask = merged_narrow ? (mask & ~(3u | (7u << 8))) : mask;
-    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + ((merged_narrow && (mask & (3u | (7u << 8)))) ? 1 : 0) + (Lmax > 1024 ? 1 : 0);
+    const unsigned kmask = merged_narrow ? (mask & ~3u) : mask;
+    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0);
     LaunchFan fan;
     fan.main_stream = stream;
     fan.aux = (hipStream_t *)aux_streams;
