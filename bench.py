@@ -761,7 +761,7 @@ def realtext_main(args, rk):
     counter = [0]
     last = [None]
 
-    def one(ap, ag, buf):
+    def one(ap, ag, buf, T_len=T_len, S_len=S_len, hints=hints):
         xp, xg, tp, tg = buf
         if args.separate_post:  # A/B: the post-DP stages as separate calls behind the joined alignment (round 2's order)
             (rp, sp), (rg, sg) = align_heads([ap, ag], [xp, xg], [tp, tg], T_len, S_len, class_masks=hints)
@@ -775,7 +775,28 @@ def realtext_main(args, rk):
                                            post={"extend": True, "boundary_softness": soft})
         return [(rp, rp.conf, rp.conf_status), (rg, rg.conf, rg.conf_status)]
 
+    nch = max(1, args.chunks)
+    cb = -(-B // nch)
+    ch_hints = [vd.class_mask_hint([T] * cb, [S] * cb, has_sil=True, n_classes=67),
+                vd.class_mask_hint([T] * cb, [S] * cb, has_sil=True, n_classes=17)]
+    cc = [0]
+
     def run_steps(n):
+        if nch > 1:  # A/B: the batch as `--chunks` calls of B / chunks utterances, round-robin over the streams in flight
+            for _ in range(n):
+                i = counter[0]
+                counter[0] += 1
+                for j in range(nch):
+                    k = cc[0] % nfl
+                    cc[0] += 1
+                    sl = slice(j * cb, min(B, (j + 1) * cb))
+                    sub = tuple(t[sl] for t in bufs[i % nbuf])
+                    if streams[k] is None:
+                        last[0] = one(*slots[k], sub, T_len[sl], S_len[sl], ch_hints)
+                    else:
+                        with torch.cuda.stream(streams[k]):
+                            last[0] = one(*slots[k], sub, T_len[sl], S_len[sl], ch_hints)
+            return
         for _ in range(n):
             i = counter[0]
             counter[0] += 1
@@ -979,6 +1000,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: ONE unsorted mixed-length call T~U{200..3000}, S=T//25")
     ap.add_argument("--global-batch", type=int, default=32768, help="c4: utterances over all ranks")
+    ap.add_argument("--chunks", type=int, default=1, help="realtext A/B: the batch as this many bfa_align_heads calls per step")
     ap.add_argument("--halves", type=int, default=1,
                     help="c4: sub-shards of a rank's shard aligned side by side (own stream / decoder / library handle each)")
     ap.add_argument("--chunk", type=int, default=16384, help="c4: utterances per bfa_align_batch call (one call per rank when the shard is smaller)")

@@ -570,3 +570,80 @@ def test_planner_falls_back_to_the_global_scratch(ora, gpu_device):
     res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=10)
     assert (exp["status"] == 0).all()
     _compare(res, exp, T_len)
+
+
+def test_staged_and_tuple_per_lane_post_stages_agree(ora, gpu_device):
+    """bfa_postprocess / bfa_confidences run in k_postconf (probed probabilities staged in LDS) when the shapes fit its
+    LDS, else in the tuple-per-lane kernels (k_postprocess, k_conf).  The same tuples through both -- the second time in
+    a segment array padded to a capacity the staging cannot hold -- must give identical rows and confidence bits, and
+    both must equal the oracle's chain; with and without the soft-boundary extension, softness 3 and 6."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch
+    from bournemouth_forced_aligner_amd.utils import postprocess_batch
+    rng = np.random.default_rng(2027)
+    C = 67
+    lp, tk, T_len, S_len = _mk_batch(rng, 24, C, (150, 700), (5, 60), peak=float(rng.choice([6.0, 3.0])), sigma=1.5,
+                                     sil_rate=0.15, sil_len=(10, 40), repeat_rate=0.05)
+    lpd = torch.from_numpy(lp).to(gpu_device)
+    res = AlignmentUtils(C - 1, 0).decode_alignments_device(lpd, torch.from_numpy(tk), T_len, S_len)
+    torch.cuda.synchronize()
+    assert (res.status.cpu().numpy() == 0).all()
+    cap = res.segs.shape[1]
+    big = 2000  # 68 bytes of LDS per tuple (records + 2 K staged cells): > 60 KB, the staging kernel declines; <= 6500
+    Sd = torch.from_numpy(np.asarray(S_len, np.int32))
+    for extend, soft in ((True, 3), (True, 6), (False, 3)):
+        s1, n1 = res.segs.clone(), res.seg_count.clone()
+        s2 = torch.zeros((lp.shape[0], big, 4), dtype=torch.int32, device=gpu_device)
+        s2[:, :cap] = res.segs
+        n2 = res.seg_count.clone()
+        postprocess_batch(lpd, Sd, s1, n1, extend=extend, boundary_softness=soft)
+        postprocess_batch(lpd, Sd, s2, n2, extend=extend, boundary_softness=soft)
+        c1, st1 = calculate_confidences_batch(lpd, s1, n1)
+        c2, st2 = calculate_confidences_batch(lpd, s2, n2)
+        torch.cuda.synchronize()
+        assert torch.equal(n1, n2) and torch.equal(st1, st2)
+        n = n1.cpu().numpy()
+        a1, a2 = s1.cpu().numpy(), s2.cpu().numpy()
+        b1, b2 = c1.cpu().numpy(), c2.cpu().numpy()
+        segs0, cnt0 = res.segs.cpu().numpy(), res.seg_count.cpu().numpy()
+        for b in range(lp.shape[0]):
+            np.testing.assert_array_equal(a1[b, :n[b]], a2[b, :n[b]], err_msg=f"rows item {b} extend={extend}")
+            assert (b1[b, :n[b]].view(np.int32) == b2[b, :n[b]].view(np.int32)).all(), f"confidences item {b}"
+            tup = [tuple(int(v) for v in r) for r in segs0[b, :cnt0[b]]]
+            cov = ora.ensure_target_coverage_default(tup, int(S_len[b]))
+            ext = (ora.extend_soft_boundaries(lp[b], cov, soft) if extend else cov) if cov else []
+            assert [tuple(int(v) for v in r) for r in a1[b, :n[b]]] == [tuple(e[:4]) for e in ext], f"oracle rows item {b}"
+            if ext:
+                rc, oc, _, _ = ora.confidences(lp[b], ext)
+                assert rc == 0 and (b1[b, :n[b]].view(np.int32) == oc.view(np.int32)).all(), f"oracle confidences item {b}"
+
+
+def test_one_kernel_small_batch_path(ora, gpu_device):
+    """Small batches of ONE sliding-window class go through k_one (plan + window DP + full-layout rerun + walk in one
+    kernel): peaky posteriors (window result used), flat posteriors (every utterance rerun with the full layout: the
+    score ends at the sentinel) and a batch with an empty, a proportional and a too-short utterance among them, both
+    head widths and both final-state rules, against the oracle; the same batches with the path switched off by the hint
+    (no hint -> every class kernel) must give the same arrays."""
+    for C in (67, 17):
+        for peak, tf in ((9.0, True), (0.3, True), (0.5, False), (6.0, False)):
+            rng = np.random.default_rng(int(peak * 10) + C + int(tf))
+            lps, toks = [], []
+            for k in range(20):
+                T = int(rng.integers(560, 640)); S = int(rng.integers(18, 20))   # L = 73..77 -> Rw = 1, rerun class R = 2
+                if k == 3: S = 0
+                if k == 5: T, S = 19, 19                                           # stride 1 / proportional
+                if k == 7: T, S = 9, 12                                            # audio too short
+                lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=C - 1, peak=peak, sigma=1.0, repeat_rate=0.1)
+                lps.append(lp); toks.append(tk)
+            lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, C - 1)
+            res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=10, tf=tf)   # host lengths -> hint -> k_one
+            _compare(res, exp, T_len)
+            from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+            au = AlignmentUtils(C - 1, 0, silence_anchors=10, truly_forced=tf)
+            hint = au.viterbi_decoder.class_mask_hint(T_len, S_len, False, n_classes=C)
+            assert hint == (1 << 8) | _lib.HINT_NO_SILENCE_TARGETS     # what bfa_launch_align takes the one-kernel path on
+            plain = au.viterbi_decoder.align_batch(torch.from_numpy(lp).to(gpu_device), torch.from_numpy(tk), T_len, S_len,
+                                                   seg_cap=lp.shape[1] + 1, class_mask=None)   # no hint: the class kernels
+            torch.cuda.synchronize()
+            assert torch.equal(plain.status, res.status) and torch.equal(plain.seg_count, res.seg_count)
+            ok = (res.status == 0)
+            assert torch.equal(plain.frame_phonemes[ok], res.frame_phonemes[ok]) and torch.equal(plain.frame_phonemes_idx[ok], res.frame_phonemes_idx[ok])
