@@ -255,7 +255,6 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     a.k2_sel = K2_ALL;
     a.k2_fused_rle = fused_k2 ? 1 : 0;
     a.k2_per_class = per_class_k2 ? 1 : 0;
-    { static const int pm = [] { const char *e = getenv("BFA_PRIO"); return e ? atoi(e) : 0; }(); a.prio_mode = (mode == 0 && (mask & 0x78u)) ? pm : 0; } // (experiment)
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
     {

@@ -97,7 +97,6 @@ struct AlignArgs {
     int32_t k2_sel;         // K2: which items this launch takes (K2_ALL / K2_FULL + R / K2_BIG / K2_REST)
     int32_t k2_fused_rle;   // K2: every utterance is one item and the walk also emits its tuples (no K3a launch)
     int32_t k2_per_class;   // launcher: one K2 launch per full-layout class behind its K1 kernel(s), K2_REST after the join
-    int32_t prio_mode;      // (experiment) wave priorities of the narrow consumers / wide producers in mixed-length calls
     int32_t k2_windows;     // launcher: the window items are walked behind the window kernels on their stream (K2_WIN)
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
