@@ -223,6 +223,18 @@ def headline_main(args, rk):
             wide[:, :, :C] = lp
             padded.append((wide[:, :, :C], tk))  # a [B,T,C] view with row stride `row_pitch`
         bufs = padded
+    if args.place_align:  # A/B: the posteriors at a chosen address alignment (+ offset) instead of wherever the caching allocator put them
+        placed = []
+        for lp, tk in bufs:
+            nbytes = lp.numel() * 4
+            raw = torch.empty(nbytes + args.place_align + args.place_offset + 512, dtype=torch.uint8, device=dev)
+            off = (-raw.data_ptr()) % args.place_align + args.place_offset
+            view = raw[off:off + nbytes].view(torch.float32).view(lp.shape)
+            view.copy_(lp)
+            placed.append((view, tk))
+        bufs = placed
+    if os.environ.get("BFA_BENCH_DUMP_K1"):
+        print("posterior buffers: " + " ".join(f"0x{lp.data_ptr():x} (mod 2 MiB = {lp.data_ptr() % (1 << 21)})" for lp, _ in bufs), file=sys.stderr)
     T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
     S_len = torch.full((B,), S, dtype=torch.int32, device=dev)
     # the product's own helper (inflight.py): one decoder (= library handle, workspace, outputs) per batch in flight;
@@ -321,6 +333,9 @@ def headline_main(args, rk):
     nk = lib.bfa_profile_collect(hs[0], kbuf, n_leg)
     k1_alone = [float(kbuf[i]) for i in range(nk)]
     kernel_ms = float(np.mean(k1_alone)) if nk else float("nan")
+    if os.environ.get("BFA_BENCH_DUMP_K1"):
+        print(f"k1 series (ms), kernel leg, buffers cycle mod {nbuf}:", " ".join(f"{v:.3f}" for v in k1_alone), file=sys.stderr)
+        print("k1 mean per buffer (ms):", " ".join(f"{np.mean(k1_alone[j::nbuf]):.4f}" for j in range(nbuf)), file=sys.stderr)
 
     # confidence pass (utils._calculate_confidences), timed separately: it is a separate reference call
     lp0, _ = bufs[(counter[0] - 1) % nbuf]
@@ -406,6 +421,8 @@ def headline_main(args, rk):
                                  "events on its launch stream -- no launch overlaps another, so this is the figure "
                                  "`rocprofv3 --kernel-trace --stats -- python bench.py --inflight 1` reports",
                          "kernel_ms": kernel_ms, "kernel_ms_stats": _stats(k1_alone), "kernel_ms_samples": int(nk),
+                         "kernel_ms_per_buffer": [float(np.mean(k1_alone[j::nbuf])) for j in range(nbuf)] if nk else None,
+                         "kernel_ms_per_buffer_what": "the kernel leg cycles through the resident batches; K1 takes 0.32 or 0.34 ms depending on where a batch physically lives (profiles/r03_placement.txt)",
                          "kernel_leg_ms_per_step": leg_ms,
                          "whole_step_frac": alg_bytes / (elapsed / total_steps) / 1e9 / HBM_PEAK_GBS,
                          "in_flight": {"what": "K1 brackets of the reported windows: with several batches in flight the "
@@ -1000,6 +1017,8 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: ONE unsorted mixed-length call T~U{200..3000}, S=T//25")
     ap.add_argument("--global-batch", type=int, default=32768, help="c4: utterances over all ranks")
+    ap.add_argument("--place-align", type=int, default=0, help="headline A/B: copy the posteriors to addresses aligned to this many bytes (0 = leave them where the allocator put them)")
+    ap.add_argument("--place-offset", type=int, default=0, help="headline A/B: ... plus this offset")
     ap.add_argument("--chunks", type=int, default=1, help="realtext A/B: the batch as this many bfa_align_heads calls per step")
     ap.add_argument("--halves", type=int, default=1,
                     help="c4: sub-shards of a rank's shard aligned side by side (own stream / decoder / library handle each)")

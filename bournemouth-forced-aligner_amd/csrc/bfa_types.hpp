@@ -154,6 +154,16 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // The window result is only valid while path scores stay above the sentinel -1000 (otherwise the item is redone with
 // the full layout, which costs more than never trying): scores are sums of per-frame log-probabilities, so long
 // utterances cross it even with good posteriors.  Past WIN_MAX_FRAMES frames the planner does not try the window.
+// band / window changes as cold branches (laid out off the straight path: the common frame falls through): A/B switch,
+// measured slower for the headline K1 (0.321 -> 0.341 ms) and without effect on a lone chain, so off
+#ifndef BFA_COLD_BAND
+#define BFA_COLD_BAND 0
+#endif
+#if BFA_COLD_BAND
+#define BFA_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define BFA_UNLIKELY(x) (x)
+#endif
 constexpr int WIN_MAX_FRAMES = 1536;
 // ... and every token costs the path at least one frame in a blank state; with a model that does not put noise between
 // phonemes that is about -15 per token after the boost, so past ~64 tokens the -1000 line is usually crossed too.
