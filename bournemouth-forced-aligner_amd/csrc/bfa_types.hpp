@@ -154,6 +154,29 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // The window result is only valid while path scores stay above the sentinel -1000 (otherwise the item is redone with
 // the full layout, which costs more than never trying): scores are sums of per-frame log-probabilities, so long
 // utterances cross it even with good posteriors.  Past WIN_MAX_FRAMES frames the planner does not try the window.
+// Workgroup id -> utterance slot (A/B switch, off).  The dispatcher places workgroup w on XCD w % 8, so with slot = w every
+// XCD streams every eighth utterance; with BFA_XCD_CHUNK = G an XCD takes chunks of G consecutive utterances (chunk c on XCD
+// c % 8).  Measured (tools/r3_remap.sh, r3_chunk_remap.sh; profiles/r03_placement.txt): whole eighths of a uniform batch per
+// XCD 0.3215 -> 0.3127 ms for the headline K1 in three interleaved pairs, but a call whose utterances are ordered by length
+// then loads one XCD with all the long ones (C4 7.4 -> 11.7 ms, one rank's shard 1.28 -> 2.68 ms); chunks of 4 / 16 / 64 / 256
+// stay within the +-3 % that the placement of the posterior buffer decides anyway, and cost mixed-length calls 1-2 %.
+// Bijective on [0, n) for any n: the last, incomplete round of chunks keeps slot = w.
+#ifndef BFA_XCD_CHUNK
+#define BFA_XCD_CHUNK 0 // (0: slot = w)
+#endif
+__host__ __device__ inline int xcd_slot(int w, int n)
+{
+#if BFA_XCD_CHUNK > 0
+    constexpr int G = BFA_XCD_CHUNK;
+    const int full = n - n % (8 * G);
+    if (w >= full) return w;
+    const int x = w & 7, s = w >> 3;
+    return ((s / G) * 8 + x) * G + s % G;
+#else
+    return w;
+#endif
+}
+
 // band / window changes as cold branches (laid out off the straight path: the common frame falls through): A/B switch,
 // measured slower for the headline K1 (0.321 -> 0.341 ms) and without effect on a lone chain, so off
 #ifndef BFA_COLD_BAND

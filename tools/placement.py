@@ -39,10 +39,24 @@ def k1(au, lp, tk, n=12):
     return float(np.mean([buf[i] for i in range(m)]))
 
 
+def stream_ms(lp, n=10):
+    """a plain sequential read of the same buffer (torch.sum), ms per pass"""
+    for _ in range(2):
+        lp.sum()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        lp.sum()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
 def report(tag, bufs):
     for j, (lp, tk) in enumerate(bufs):
         row = " ".join(f"{k1(au, lp, tk):.4f}" for au in decs)
-        print(f"{tag} buffer {j} at 0x{lp.data_ptr():x}: K1 ms per decoder: {row}", flush=True)
+        print(f"{tag} buffer {j} at 0x{lp.data_ptr():x}: K1 ms per decoder: {row}; torch.sum {stream_ms(lp):.4f} ms", flush=True)
 
 
 bufs = [synth_batch(B, T, S, C, 1003 + 1000 * i, dev) for i in range(N)]
@@ -87,4 +101,4 @@ for flag, name in ((0x4, "contiguous"), (0x0, "default hipMalloc")):
         t = torch.as_tensor(_Raw(p.value, lp.shape), device=dev)
         t.copy_(lp)
         contig.append((t, tk))
-        print(f"{name} buffer at 0x{p.value:x}: K1 ms per decoder: " + " ".join(f"{k1(au, t, tk):.4f}" for au in decs), flush=True)
+        print(f"{name} buffer at 0x{p.value:x}: K1 ms per decoder: " + " ".join(f"{k1(au, t, tk):.4f}" for au in decs) + f"; torch.sum {stream_ms(t):.4f} ms", flush=True)

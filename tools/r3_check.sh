@@ -1,7 +1,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd $ROOT
 j() { python -c "import json,sys; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$1', 'ms/step %.4f' % d['ms_per_step'], (d.get('roofline') or {}).get('kernel_ms'), (d.get('roofline') or {}).get('frac'), d.get('status_ok', (d.get('parity_sample') or d.get('parity') or {})))"; }
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-BFA_HIP_LIBRARY=$ROOT/bournemouth-forced-aligner_amd/variants/libbfa_t_base.so python tools/lone_times.py 2>&1 | grep "^B="
+
 python tools/latency_device.py 2>&1 | grep "B=\|sync"
 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | j headline
 python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | j headline
