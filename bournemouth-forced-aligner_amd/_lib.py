@@ -13,6 +13,7 @@ BFA_ERR_INVALID_ARGUMENT, BFA_ERR_NO_DEVICE, BFA_ERR_LAUNCH = -1, -2, -3
 BFA_ERR_WORKSPACE_TOO_SMALL, BFA_ERR_UNSUPPORTED = -4, -5
 ITEM_OK, ITEM_TOO_SHORT, ITEM_BAD_TOKEN, ITEM_TOO_LARGE, ITEM_SEG_OVERFLOW, ITEM_BAD_HINT = 0, 1, 2, 3, 4, 5
 HINT_NO_SILENCE_TARGETS = 1 << 16
+HINT_UNIFORM_LENGTHS = 1 << 17
 MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",

@@ -226,7 +226,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
     const int Lmax = 4 * a.Smax + 1;
     unsigned mask = r_class_mask_upto(Lmax);
-    if (p.class_mask) mask &= p.class_mask;
+    if (p.class_mask & 0xffffu) mask &= p.class_mask; // (flag bits alone are not a class selection)
     const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0 && !(p.class_mask & BFA_HINT_NO_SILENCE_TARGETS);
     const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
     // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
@@ -236,7 +236,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
         for (int rw = 8; rw >= 1; --rw) // drop the classes above the one the longest possible path would take
             if (top > 0 && rw > top) wmask &= ~(1u << (rw - 1));
-        if (p.class_mask) wmask &= (p.class_mask >> 8);
+        if (p.class_mask & 0xffffu) wmask &= (p.class_mask >> 8);
     }
     // (the window result is exact because emissions are <= 0; a floor above log(1) = 0 would break that argument)
     if (!(p.min_logp <= 0.0f)) wmask = 0;
@@ -255,6 +255,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     a.k2_sel = K2_ALL;
     a.k2_fused_rle = fused_k2 ? 1 : 0;
     a.k2_per_class = per_class_k2 ? 1 : 0;
+    a.xcd_contig = (mode == 0 && (p.class_mask & BFA_HINT_UNIFORM_LENGTHS)) ? 1 : 0;
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
     {

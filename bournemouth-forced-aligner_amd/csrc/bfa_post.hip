@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
     float *sp = (float *)(whi + a.seg_cap);
     const int lane = threadIdx.x & 63;
     const double th1 = a.th1, th2 = a.th2;
-    for (int b = bfa::xcd_slot((int)blockIdx.x, (int)gridDim.x); b < a.B; b += gridDim.x) {
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         bfa_segment *sg = a.segs + (int64_t)b * a.seg_cap;
         const LpView<RAW> lp{a.logp + (int64_t)b * a.strideB, a.strideT,
                              RAW ? a.row_stats + 2 * (int64_t)b * a.Tmax : nullptr, a.C};

@@ -97,6 +97,7 @@ struct AlignArgs {
     int32_t k2_sel;         // K2: which items this launch takes (K2_ALL / K2_FULL + R / K2_BIG / K2_REST)
     int32_t k2_fused_rle;   // K2: every utterance is one item and the walk also emits its tuples (no K3a launch)
     int32_t k2_per_class;   // launcher: one K2 launch per full-layout class behind its K1 kernel(s), K2_REST after the join
+    int32_t xcd_contig;     // K1 (one item per workgroup): slot = xcd_eighth(workgroup id) (BFA_HINT_UNIFORM_LENGTHS)
     int32_t k2_windows;     // launcher: the window items are walked behind the window kernels on their stream (K2_WIN)
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
@@ -154,27 +155,16 @@ __host__ __device__ inline unsigned r_class_bit(int R)
 // The window result is only valid while path scores stay above the sentinel -1000 (otherwise the item is redone with
 // the full layout, which costs more than never trying): scores are sums of per-frame log-probabilities, so long
 // utterances cross it even with good posteriors.  Past WIN_MAX_FRAMES frames the planner does not try the window.
-// Workgroup id -> utterance slot (A/B switch, off).  The dispatcher places workgroup w on XCD w % 8, so with slot = w every
-// XCD streams every eighth utterance; with BFA_XCD_CHUNK = G an XCD takes chunks of G consecutive utterances (chunk c on XCD
-// c % 8).  Measured (tools/r3_remap.sh, r3_chunk_remap.sh; profiles/r03_placement.txt): whole eighths of a uniform batch per
-// XCD 0.3215 -> 0.3127 ms for the headline K1 in three interleaved pairs, but a call whose utterances are ordered by length
-// then loads one XCD with all the long ones (C4 7.4 -> 11.7 ms, one rank's shard 1.28 -> 2.68 ms); chunks of 4 / 16 / 64 / 256
-// stay within the +-3 % that the placement of the posterior buffer decides anyway, and cost mixed-length calls 1-2 %.
-// Bijective on [0, n) for any n: the last, incomplete round of chunks keeps slot = w.
-#ifndef BFA_XCD_CHUNK
-#define BFA_XCD_CHUNK 0 // (0: slot = w)
-#endif
-__host__ __device__ inline int xcd_slot(int w, int n)
+// Workgroup id -> utterance slot with every XCD on ONE contiguous eighth of the batch (the dispatcher places workgroup w on
+// XCD w % 8, so with slot = w every XCD streams every eighth utterance).  Used when the caller says the utterances of the
+// call have about the same number of frames (BFA_HINT_UNIFORM_LENGTHS -> AlignArgs::xcd_contig): headline K1 0.3215 -> 0.3127 ms
+// in three interleaved pairs; without that promise a call ordered by length would put all the long utterances on one XCD
+// (C4 7.4 -> 11.7 ms), and chunked forms (4 ... 256 utterances per XCD turn) stay within the +-3 % that the placement of the
+// posterior buffer decides anyway (profiles/r03_placement.txt).  Bijective on [0, n) for any n.
+__host__ __device__ inline int xcd_eighth(int w, int n)
 {
-#if BFA_XCD_CHUNK > 0
-    constexpr int G = BFA_XCD_CHUNK;
-    const int full = n - n % (8 * G);
-    if (w >= full) return w;
-    const int x = w & 7, s = w >> 3;
-    return ((s / G) * 8 + x) * G + s % G;
-#else
-    return w;
-#endif
+    const int q = n >> 3, r = n & 7, x = w & 7;
+    return x * q + (x < r ? x : r) + (w >> 3);
 }
 
 // band / window changes as cold branches (laid out off the straight path: the common frame falls through): A/B switch,

@@ -217,8 +217,8 @@ class ViterbiDecoder:
         the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`).
         `has_sil` says whether any target may contain the silence id (then the segmented mode can create
         shorter DPs, and every full class up to the largest is kept; otherwise bit 16 tells the library to
-        skip the silence planning, and a target that does contain it is reported as ITEM_BAD_HINT).  Without a hint the library launches
-        every class the tensor shapes allow."""
+        skip the silence planning, and a target that does contain it is reported as ITEM_BAD_HINT).  Bit 17 (a speed hint) says the
+        utterances have about the same number of frames.  Without a hint the library launches every class the tensor shapes allow."""
         T = np.asarray(list(T_lens) if not isinstance(T_lens, np.ndarray) else T_lens, dtype=np.int64).reshape(-1)
         S = np.asarray(list(S_lens) if not isinstance(S_lens, np.ndarray) else S_lens, dtype=np.int64).reshape(-1)
         if T.size == 0:
@@ -260,6 +260,8 @@ class ViterbiDecoder:
             mask |= (1 << (top + 1)) - 1                         # speech segments can be any shorter class
         if not has_sil and mask:
             mask |= _lib.HINT_NO_SILENCE_TARGETS  # the silence-anchored planning kernels are not launched
+        if mask and T.size >= 64 and int(T.max() - T.min()) * 8 <= int(T.max()):
+            mask |= _lib.HINT_UNIFORM_LENGTHS     # about the same number of frames everywhere: one contiguous eighth of the batch per XCD
         return mask
 
     def _prepare_call(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,

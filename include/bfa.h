@@ -63,6 +63,7 @@ typedef enum {
                                    although the target contains silence_id, or a K1 class bit that is missing */
 
 #define BFA_HINT_NO_SILENCE_TARGETS (1 << 16)
+#define BFA_HINT_UNIFORM_LENGTHS (1 << 17)
 
 /* per-utterance decode mode written to out_mode[b] */
 #define BFA_MODE_EMPTY 0        /* S == 0 -> no segments (forced_alignment.py:894-897) */
@@ -88,6 +89,10 @@ typedef struct {
                                   bits 8-15 sliding-window classes Rw in {1,2,3,4,6,8} (bit 7+Rw),
                                   bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
                                             silence-anchored planning kernels are not launched.
+                                  bit 17    BFA_HINT_UNIFORM_LENGTHS: the utterances of this call have about the same
+                                            number of frames (a speed hint only: each XCD then takes one contiguous
+                                            eighth of the batch; with very different lengths ordered by length it
+                                            would load the XCDs unevenly -- results are the same either way).
                                   A hint that excludes what an utterance needs is reported as BFA_ITEM_BAD_HINT. */
     int32_t window_max_tokens; /* 0 = 64.  K1's sliding-window variant is exact only while the path score stays above
                                   the reference's -1000 sentinel; otherwise the utterance is redone with the full state

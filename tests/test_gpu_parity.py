@@ -647,3 +647,35 @@ def test_one_kernel_small_batch_path(ora, gpu_device):
             assert torch.equal(plain.status, res.status) and torch.equal(plain.seg_count, res.seg_count)
             ok = (res.status == 0)
             assert torch.equal(plain.frame_phonemes[ok], res.frame_phonemes[ok]) and torch.equal(plain.frame_phonemes_idx[ok], res.frame_phonemes_idx[ok])
+
+
+def test_uniform_lengths_hint_only_moves_the_work(ora, gpu_device):
+    """BFA_HINT_UNIFORM_LENGTHS lets each XCD take one contiguous eighth of the batch (workgroup id -> utterance slot through
+    xcd_eighth): the same arrays as without the hint, for batch sizes that are and are not multiples of 8, in the window,
+    the narrow full-layout and a split wide class; and against the oracle."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+    C = 67
+    for B, T, S in ((77, 600, 20), (64, 300, 30), (9, 400, 16), (67, 900, 100)):
+        rng = np.random.default_rng(B * 1000 + T)
+        lps, toks = [], []
+        for k in range(B):
+            lp, tk, _ = cases.planted_case(rng, T - int(rng.integers(0, T // 10)), S - int(rng.integers(0, 3)), C=C, blank=C - 1, peak=7.0, sigma=1.0)
+            lps.append(lp); toks.append(tk)
+        lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, C - 1)
+        au = AlignmentUtils(C - 1, 0, silence_anchors=10)
+        vd = au.viterbi_decoder
+        hint = vd.class_mask_hint(T_len, S_len, False, n_classes=C) & ~_lib.HINT_UNIFORM_LENGTHS
+        lpd, tkd = torch.from_numpy(lp).to(gpu_device), torch.from_numpy(tk)
+        plain = vd.align_batch(lpd, tkd, T_len, S_len, seg_cap=lp.shape[1] + 1, class_mask=hint)
+        moved = vd.align_batch(lpd, tkd, T_len, S_len, seg_cap=lp.shape[1] + 1, class_mask=hint | _lib.HINT_UNIFORM_LENGTHS)
+        torch.cuda.synchronize()
+        assert (plain.status.cpu().numpy() == 0).all()
+        for name in ("status", "seg_count", "mode"):
+            assert torch.equal(getattr(plain, name), getattr(moved, name)), (B, T, S, name)
+        cnt = plain.seg_count.cpu().numpy()
+        for b in range(B):  # (rows past seg_count and frames past T_len are unspecified)
+            assert torch.equal(plain.segs[b, :cnt[b]], moved.segs[b, :cnt[b]]), (B, T, S, b)
+            for name in ("frame_phonemes", "frame_phonemes_idx"):
+                assert torch.equal(getattr(plain, name)[b, :T_len[b]], getattr(moved, name)[b, :T_len[b]]), (B, T, S, b, name)
+        exp = ora.decode_alignments(lp, tk, T_len, S_len, ora.make_params(C - 1, 0, 10, True, True, True, True))
+        _compare(moved, exp, T_len)

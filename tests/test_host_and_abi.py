@@ -116,6 +116,11 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
     assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001       # T > 1536: full layout
     assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 13     # L=721, bw=180 -> 372 states -> Rw=6
+    # bit 17 (speed hint): 64 or more utterances with about the same number of frames
+    from bournemouth_forced_aligner_amd._lib import HINT_UNIFORM_LENGTHS as UL
+    assert vd.class_mask_hint([1000] * 64, [40] * 64, has_sil=False, n_classes=67) == NS | UL | 1 << 9
+    assert vd.class_mask_hint([1000] * 63 + [900], [40] * 64, has_sil=False, n_classes=67) == NS | UL | 1 << 9
+    assert vd.class_mask_hint([1000] * 63 + [500], [40] * 63 + [20], has_sil=False, n_classes=67) == NS | 1 << 9 | 1 << 8
     assert vd.class_mask_hint([900], [187], has_sil=False, n_classes=67) == NS | 1 << 15     # L=749, bw=187 -> 390 states -> Rw=8
     assert vd.class_mask_hint([1200], [250], has_sil=False, n_classes=67) == NS | 1 << 6     # L=1001, bw=250: 516 states > 512 -> full R=16
     assert vd.class_mask_hint([], [], has_sil=False) == 0
