@@ -248,6 +248,8 @@ def headline_main(args, rk):
     # the lengths are known on the host (constant here), and the synthetic targets never contain SIL:
     # tell the library which K1 register class occurs so that it does not launch the empty ones
     hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False, n_classes=(None if args.no_window else C))
+    if args.no_uniform_hint:  # A/B: workgroup w = utterance w instead of one contiguous eighth of the batch per XCD
+        hint &= ~_lib.HINT_UNIFORM_LENGTHS
     counter = [0]
     last = [None]
 
@@ -1017,6 +1019,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="side measurement: ONE unsorted mixed-length call T~U{200..3000}, S=T//25")
     ap.add_argument("--global-batch", type=int, default=32768, help="c4: utterances over all ranks")
+    ap.add_argument("--no-uniform-hint", action="store_true", help="headline A/B: drop BFA_HINT_UNIFORM_LENGTHS from the class hint")
     ap.add_argument("--place-align", type=int, default=0, help="headline A/B: copy the posteriors to addresses aligned to this many bytes (0 = leave them where the allocator put them)")
     ap.add_argument("--place-offset", type=int, default=0, help="headline A/B: ... plus this offset")
     ap.add_argument("--chunks", type=int, default=1, help="realtext A/B: the batch as this many bfa_align_heads calls per step")

@@ -1,13 +1,12 @@
 #!/bin/bash
-# tools/r3_remap.sh -- headline K1 with every XCD on a contiguous range of utterances (the build) against workgroup id = utterance
-# (variant noremap), per resident batch, interleaved
+# tools/r3_remap.sh -- headline K1 with BFA_HINT_UNIFORM_LENGTHS (each XCD on one contiguous eighth of the batch) against
+# workgroup id = utterance (--no-uniform-hint), per resident batch, interleaved processes
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd $ROOT
-run() { BFA_BENCH_DUMP_K1=1 python bench.py --steps 20 --warmup 5 --no-cpu "$@" 2>&1 | grep "mean per buffer\|^{" | python -c "
+run() { python bench.py --steps 20 --warmup 5 --no-cpu "$@" 2>/dev/null | grep "^{" | tail -1 | python -c "
 import sys, json
-for l in sys.stdin:
-    if l.startswith('{'): d = json.loads(l); print('   ms/step %.4f  K1 %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))
-    else: print('  ', l.strip())"; }
+d = json.loads(sys.stdin.read()); r = d['roofline']
+print('   ms/step %.4f  K1 %.4f  per batch %s' % (d['ms_per_step'], r['kernel_ms'], ' '.join('%.4f' % v for v in r['kernel_ms_per_buffer'])))"; }
 for i in 1 2 3; do
-echo "remap"; run
-echo "no remap"; BFA_HIP_LIBRARY=$ROOT/bournemouth-forced-aligner_amd/variants/libbfa_noremap.so run
+echo "eighth per XCD"; run
+echo "workgroup = utterance"; run --no-uniform-hint
 done
