@@ -563,6 +563,8 @@ def c4_main(args, rk):
     from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
     au = AlignmentUtils(blank_id=blank, silence_id=0)
     vd = au.viterbi_decoder
+    vd.window_max_frames = args.win_frames or None   # (A/B: how long an utterance may be for K1 to try its sliding window)
+    vd.window_max_tokens = args.win_tokens or None
     lib = _lib.lib()
     h = _lib.handle(rk.local_rank)
 
@@ -602,6 +604,7 @@ def c4_main(args, rk):
     for k in range(1, nlanes):
         a2 = AlignmentUtils(blank_id=blank, silence_id=0)
         a2.viterbi_decoder.handle_slot = k
+        a2.viterbi_decoder.window_max_frames, a2.viterbi_decoder.window_max_tokens = vd.window_max_frames, vd.window_max_tokens
         aus.append(a2)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nlanes)] if nlanes > 1 else None
     step_no = [0]
