@@ -8,6 +8,7 @@ timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; echo "p
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $OUT/smoke.log
 python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | last > $OUT/bench.json
 python bench.py --steps 20 --warmup 5 --inflight 1 --no-cpu 2>/dev/null | last > $OUT/bench_inflight1.json
+rm -f $OUT/bench_runs.jsonl; for i in 1 2 3 4 5 6; do python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | last >> $OUT/bench_runs.jsonl; done
 python bench.py --config realtext --steps 20 --warmup 5 2>$OUT/realtext.err | last > $OUT/realtext.json
 python bench.py --config realtext --steps 20 --warmup 5 --inflight 1 --parity-sample 0 2>/dev/null | last > $OUT/realtext_inflight1.json
 python bench.py --config realtext --steps 20 --warmup 5 --inflight 1 --hw-queues 4 --parity-sample 0 2>/dev/null | last > $OUT/realtext_inflight1_q4.json
@@ -31,6 +32,7 @@ for d in st_inflight1 st_default st_realtext st_c4 st_sil st_pipeline; do cp $(f
 bash tools/timeline.sh r3f_realtext 2 python $ROOT/bench.py --config realtext --steps 5 --warmup 2 --settle-ms 0 --min-timed-steps 5 --parity-sample 0 --inflight 1 > $OUT/realtext_timeline.txt 2>&1
 bash tools/timeline.sh r3f_ragged 1 python $ROOT/bench.py --ragged --steps 3 > $OUT/ragged_timeline.txt 2>&1
 bash tools/profile.sh r3f > $OUT/profile.log 2>&1
+bash tools/r3_pmc.sh rt_final python $ROOT/bench.py --config realtext --steps 3 --warmup 1 --settle-ms 0 --min-timed-steps 3 --parity-sample 0 --inflight 1 > $OUT/realtext_pmc_final.txt 2>&1
 python tools/prof_summary.py gpurun_out/prof_r3f > $OUT/headline_summary.txt 2>&1
 for s in 11 12 13; do timeout 900 python tests/soak.py 150 $s --record $OUT/soak.json 2>&1 | tail -1; done
 python - <<PY
