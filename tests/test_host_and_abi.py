@@ -402,3 +402,28 @@ def test_c4_generator_is_a_function_of_the_global_index_only():
     am = la[0, :T[a_idx[0]]].argmax(-1).numpy()
     runs = am[np.r_[True, am[1:] != am[:-1]]]
     assert [int(x) for x in runs if x != 66] == [int(x) for x in ta[0, :S[a_idx[0]]]]
+
+
+def test_headline_k1_keeps_eight_waves_per_simd():
+    """The headline runs in k_dp4w<2> (and small / short batches in <1>, <3>): producer + consumer pairs fill the machine
+    only at 8 waves per SIMD, i.e. <= 64 VGPRs per role with nothing spilled to scratch inside the roles; LDS must let 16
+    workgroups share a CU (<= 10 KB).  The compiler's resource remark is the check (hipcc cross-compiles without a GPU)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bournemouth-forced-aligner_amd", "csrc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                          "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", "-c",
+                          os.path.join(csrc, "bfa_dp_nk5_p4.hip"), "-o", os.devnull],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = {}
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?VGPRs Spill: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)",
+                         out.stderr, re.S):
+        res[m.group(1)] = tuple(int(m.group(k)) for k in (2, 3, 4, 5))
+    for rw in (1, 2, 3):
+        key = [k for k in res if f"k_dp4wILi{rw}ELi4ELi3ELb0E" in k]
+        assert key, sorted(res)
+        vgpr, vspill, occ, lds = res[key[0]]
+        assert vgpr <= 64 and vspill == 0 and occ == 8 and lds <= 10240, (rw, res[key[0]])
