@@ -159,9 +159,9 @@ void ora_log_softmax_rows(const float *x, long ldx, float *out, long ldo, long T
 /* ------------------------------------------------------------------------------------------
  * _viterbi_decode, forced_alignment.py:563-703
  * ---------------------------------------------------------------------------------------- */
-int ora_viterbi(const float *lp, long ldT, int T, int C, const int32_t *path, const int32_t *pidx, int L,
-                int band_width, int truly_forced, int blank, int pace_f32, int32_t *frame_ph,
-                int32_t *frame_idx, int32_t *states_out, float *final_dp_out)
+static int viterbi_impl(const float *lp, long ldT, int T, int C, const int32_t *path, const int32_t *pidx, int L,
+                        int band_width, int truly_forced, int blank, int pace_f32, int32_t *frame_ph,
+                        int32_t *frame_idx, int32_t *states_out, float *final_dp_out, uint8_t *K_out, int32_t *t_dead_out)
 {
     if (T <= 0 || L <= 0) return ORA_ERR_ARG;
     if (blank < 0 || blank >= C) return ORA_ERR_ARG;
@@ -184,6 +184,7 @@ int ora_viterbi(const float *lp, long ldT, int T, int C, const int32_t *path, co
     int use_band = (band_width > 0 && T > 1 && L > 1);
     double pace = use_band ? (double)(L - 1) / (double)(T - 1) : 0.0;
     float pace32 = use_band ? (float)(L - 1) / (float)(T - 1) : 0.0f; /* decode_alignments_simple: 0-dim tensors */
+    int t_dead = -1;
 
     for (int t = 1; t < T; t++) { /* :608-653 */
         const float *row = lp + (long)t * ldT;
@@ -215,8 +216,15 @@ int ora_viterbi(const float *lp, long ldT, int T, int C, const int32_t *path, co
                 if (fs < lo || fs > hi) nxt[s] = NEGF;
             }
         }
+        if (t_dead < 0) { /* first frame after which every state holds <= -1000 (then they all stay there: emissions <= 0) */
+            int alive = 0;
+            for (int s = 0; s < L; s++) if (nxt[s] > NEGF) { alive = 1; break; }
+            if (!alive) t_dead = t;
+        }
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
+    if (t_dead_out) *t_dead_out = (t_dead < 0) ? T : t_dead;
+    if (K_out) { memset(K_out, 0, (size_t)L); memcpy(K_out + L, K + L, (size_t)(T - 1) * (size_t)L); }
 
     int f;
     if (!truly_forced) { /* :656-666 */
@@ -248,6 +256,153 @@ int ora_viterbi(const float *lp, long ldT, int T, int C, const int32_t *path, co
         if (states_out) states_out[t] = st[t];
     }
     free(dp); free(K); free(can_skip); free(st);
+    return ORA_OK;
+}
+
+int ora_viterbi(const float *lp, long ldT, int T, int C, const int32_t *path, const int32_t *pidx, int L,
+                int band_width, int truly_forced, int blank, int pace_f32, int32_t *frame_ph,
+                int32_t *frame_idx, int32_t *states_out, float *final_dp_out)
+{
+    return viterbi_impl(lp, ldT, T, C, path, pidx, L, band_width, truly_forced, blank, pace_f32, frame_ph, frame_idx,
+                        states_out, final_dp_out, NULL, NULL);
+}
+
+/* the same recurrence, additionally handing out the codes K[T][L] (k = 0 stay / 1 advance / 2 skip; row 0 is zero) and
+ * t_dead = the first frame after which every state is at or below the -1000 sentinel (T if that never happens) */
+int ora_viterbi_trace(const float *lp, long ldT, int T, int C, const int32_t *path, const int32_t *pidx, int L,
+                      int band_width, int truly_forced, int blank, int pace_f32, int32_t *frame_ph,
+                      int32_t *frame_idx, int32_t *states_out, float *final_dp_out, uint8_t *K_out, int32_t *t_dead_out)
+{
+    return viterbi_impl(lp, ldT, T, C, path, pidx, L, band_width, truly_forced, blank, pace_f32, frame_ph, frame_idx,
+                        states_out, final_dp_out, K_out, t_dead_out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The "dead sentinel regime" of _viterbi_decode in closed form (a DERIVED property of forced_alignment.py:608-653,
+ * proved against viterbi_impl by tests/test_dead_tail.py; the HIP tail kernel implements exactly this).
+ *
+ * Premises: emissions <= 0 (log-probabilities), every state <= -1000 after some frame t_dead, and the CTC path is such
+ * that a state that can skip never follows one that can (stride 2 / 4 paths whose tokens differ from the blank id:
+ * can_skip is false for every even state).  Then for every frame t >= t_dead + 2
+ *     dp[t][s] = -1000                                      s cannot skip (c2 is the constant -1000 and wins or ties)
+ *     dp[t][s] = in_band(t, s) ? f32(-1000 + e[t][s]) : -1000   s can skip (c1 = f32(dp[t-1][s-1] + e) with dp[t-1][s-1] = -1000)
+ * i.e. a function of frame t alone, and the code of state s at frame t + 1 follows from dp[t][s], e[t+1][s]:
+ *     s cannot skip:  c2 = -1000 is the maximum; k = 0 if f32(-1000 + e) == -1000, else 2 (state 0: 1 -- c1 is the constant)
+ *     s can skip   :  c1 = f32(-1000 + e) is the maximum; k = 0 if f32(dp[t][s] + e) == c1, else 1
+ * K_out rows [t_from, T) are written.  Returns ORA_ERR_ARG when the path does not have the structure above.
+ * ---------------------------------------------------------------------------------------- */
+int ora_dead_tail_codes(const float *lp, long ldT, int T, int C, const int32_t *path, int L, int band_width,
+                        int pace_f32, int t_from, uint8_t *K_out)
+{
+    if (T <= 1 || L <= 0 || t_from < 2 || t_from > T) return ORA_ERR_ARG;
+    for (int s = 0; s < L; s++) if (path[s] < 0 || path[s] >= C) return ORA_ERR_ARG;
+    uint8_t *skip = (uint8_t *)malloc((size_t)L);
+    if (!skip) return ORA_ERR_ALLOC;
+    for (int s = 0; s < L; s++) skip[s] = (s >= 2 && path[s] != path[s - 2]) ? 1 : 0;
+    for (int s = 1; s < L; s++) if (skip[s] && skip[s - 1]) { free(skip); return ORA_ERR_ARG; }
+    const int use_band = (band_width > 0 && T > 1 && L > 1);
+    const double pace = use_band ? (double)(L - 1) / (double)(T - 1) : 0.0;
+    const float pace32 = use_band ? (float)(L - 1) / (float)(T - 1) : 0.0f;
+    for (int t = t_from; t < T; t++) {
+        const float *row = lp + (long)t * ldT, *prow = lp + (long)(t - 1) * ldT;
+        float lo = 0.0f, hi = 0.0f; /* band of frame t-1 */
+        if (use_band) {
+            if (pace_f32) { float c = (float)(t - 1) * pace32; lo = c - (float)band_width; hi = c + (float)band_width; }
+            else { double c = (double)(t - 1) * pace; lo = (float)(c - (double)band_width); hi = (float)(c + (double)band_width); }
+        }
+        uint8_t *Kt = K_out + (size_t)t * (size_t)L;
+        for (int s = 0; s < L; s++) {
+            const float e = row[path[s]];
+            if (e > 0.0f) { free(skip); return ORA_ERR_ARG; }
+            const float x = NEGF + e;
+            if (!skip[s]) {
+                Kt[s] = (x < NEGF) ? (uint8_t)(s >= 1 ? 2 : 1) : 0;
+            } else {
+                const int inb = !use_band || !((float)s < lo || (float)s > hi);
+                const float d = inb ? (NEGF + prow[path[s]]) : NEGF;
+                const float y = d + e;
+                Kt[s] = (y < x) ? 1 : 0;
+            }
+        }
+    }
+    free(skip);
+    return ORA_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The banded recurrence restricted to a sliding window of 64 * RW states (a DERIVED property of
+ * forced_alignment.py:608-653, proved against viterbi_impl by tests/test_dead_tail.py; the HIP "exact window" consumer
+ * and the walk's out-of-window rule implement exactly this).
+ *
+ * Premises: emissions <= 0, an active band (bw > 0, T > 1, L > 1) and L <= T (pace <= 1).  The window [base, base + 64 RW)
+ * moves up in steps of RW states at the start of every row of FPW frames (FPW = 16 / 8 / 4 for RW = 1 / 2 / >= 3) until
+ * base + RW > lo - 2, lo = the lower band limit of the row's first frame.  Inside the window the recurrence runs as in the
+ * reference with every state outside it taken as exactly -1000 (true: such states are out of band in the previous frame).
+ * Outside the window all three predecessors of a state are out of band, hence exactly -1000, in ANY regime:
+ *     s cannot skip:  c2 (or, for s < 2, the masked constants) = -1000 is the maximum; k = 0 if f32(-1000 + e) == -1000,
+ *                     else 2 (state 0: 1)
+ *     s can skip   :  c0 = c1 = c2 = f32(-1000 + e): k = 0
+ * K_out [T][L] receives every code, final_dp_out [L] the scores after the last frame.
+ * ---------------------------------------------------------------------------------------- */
+int ora_window_codes(const float *lp, long ldT, int T, int C, const int32_t *path, int L, int band_width, int RW,
+                     uint8_t *K_out, float *final_dp_out, int32_t *min_margin_out)
+{
+    if (T <= 1 || L <= 1 || band_width <= 0 || L > T || RW < 1) return ORA_ERR_ARG;
+    for (int s = 0; s < L; s++) if (path[s] < 0 || path[s] >= C) return ORA_ERR_ARG;
+    const int FPW = (RW == 1) ? 16 : (RW == 2) ? 8 : 4, WN = 64 * RW;
+    float *cur = (float *)malloc(sizeof(float) * (size_t)L * 2);
+    uint8_t *skip = (uint8_t *)malloc((size_t)L);
+    if (!cur || !skip) { free(cur); free(skip); return ORA_ERR_ALLOC; }
+    float *nxt = cur + L;
+    for (int s = 0; s < L; s++) { cur[s] = NEGF; skip[s] = (s >= 2 && path[s] != path[s - 2]) ? 1 : 0; }
+    cur[0] = lp[path[0]];
+    cur[1] = lp[path[1]];
+    memset(K_out, 0, (size_t)L);
+    const double pace = (double)(L - 1) / (double)(T - 1);
+    int base = 0, margin = 1 << 30;
+    for (int t = 1; t < T; t++) {
+        const float *row = lp + (long)t * ldT;
+        const float lo = (float)((double)t * pace - (double)band_width), hi = (float)((double)t * pace + (double)band_width);
+        if (t % FPW == 0) { /* the window moves between rows only */
+            const int lo4 = (int)ceilf(lo);
+            while (base + RW <= lo4 - 2) base += RW;
+        }
+        uint8_t *Kt = K_out + (size_t)t * (size_t)L;
+        for (int s = 0; s < L; s++) {
+            const float e = row[path[s]];
+            if (e > 0.0f) { free(cur); free(skip); return ORA_ERR_ARG; }
+            if (s < base || s >= base + WN) { /* outside the window: closed form, score exactly -1000 */
+                const float x = NEGF + e;
+                Kt[s] = skip[s] ? 0 : ((x < NEGF) ? (uint8_t)(s >= 1 ? 2 : 1) : 0);
+                nxt[s] = NEGF;
+                continue;
+            }
+            const float d0 = cur[s];
+            const float d1 = (s - 1 >= base) ? cur[s - 1] : NEGF; /* (below the window: -1000; cur[] of states that left it is stale) */
+            const float d2 = (s - 2 >= base) ? cur[s - 2] : NEGF;
+            const float c0 = d0 + e;
+            const float c1 = (s >= 1) ? (d1 + e) : NEGF;
+            const float c2 = (s >= 2 && skip[s]) ? (d2 + e) : NEGF;
+            int k = 0; float best = c0;
+            if (c1 > best) { k = 1; best = c1; }
+            if (c2 > best) { k = 2; best = c2; }
+            Kt[s] = (uint8_t)k;
+            nxt[s] = ((float)s < lo || (float)s > hi) ? NEGF : best;
+        }
+        { /* how far the in-band states (and the two above them) stay from the window's top: the kernel's safety margin */
+            const int ihi = (int)floorf(hi);
+            const int m = (base + WN - 1) - ((ihi < L - 1 ? ihi : L - 1) + 2);
+            if (ihi + 2 <= L - 1 + 2 && m < margin) margin = m;
+        }
+        for (int s = base + WN; s < L; s++) nxt[s] = NEGF;
+        float *tmp = cur; cur = nxt; nxt = tmp;
+        /* states entering the window at the next move must read as -1000: they do (set above); states below `base` keep
+         * stale values in cur[] but are never read again (d1 / d2 guard) */
+    }
+    for (int s = 0; s < L; s++) if (s < base) cur[s] = NEGF;
+    if (final_dp_out) memcpy(final_dp_out, cur, sizeof(float) * (size_t)L);
+    if (min_margin_out) *min_margin_out = margin;
+    free(cur < nxt ? cur : nxt); free(skip);
     return ORA_OK;
 }
 

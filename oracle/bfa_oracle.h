@@ -58,6 +58,18 @@ int ora_viterbi(const float *lp, long ldT, int T, int C, const int32_t *path, co
                 int band_width, int truly_forced, int blank, int pace_f32, int32_t *frame_ph,
                 int32_t *frame_idx, int32_t *states_out, float *final_dp_out);
 
+/* the same, also handing out the codes K[T][L] and the first all-dead frame (tests of the dead-tail closed form) */
+int ora_viterbi_trace(const float *lp, long ldT, int T, int C, const int32_t *path, const int32_t *pidx, int L,
+                      int band_width, int truly_forced, int blank, int pace_f32, int32_t *frame_ph,
+                      int32_t *frame_idx, int32_t *states_out, float *final_dp_out, uint8_t *K_out, int32_t *t_dead_out);
+/* closed form of the codes in the dead sentinel regime (derived from forced_alignment.py:608-653; see the .c) */
+int ora_dead_tail_codes(const float *lp, long ldT, int T, int C, const int32_t *path, int L, int band_width,
+                        int pace_f32, int t_from, uint8_t *K_out);
+
+/* the banded recurrence on a sliding window of 64 RW states + the closed form outside it (see the .c) */
+int ora_window_codes(const float *lp, long ldT, int T, int C, const int32_t *path, int L, int band_width, int RW,
+                     uint8_t *K_out, float *final_dp_out, int32_t *min_margin_out);
+
 /* forced_alignment.py:29-83 (boost + log_softmax + floor); out is contiguous [T,C] */
 int ora_prepare_emissions(const float *lp, long ldT, int T, int C, const int32_t *seq, int S,
                           const ora_params *p, float *out);

@@ -114,6 +114,66 @@ def viterbi(lp, path, pidx, band_width, truly_forced, blank, pace_f32=False):
     return rc, fph, fidx, states, fdp
 
 
+def viterbi_trace(lp, path, pidx, band_width, truly_forced, blank, pace_f32=False):
+    """viterbi() plus the codes K [T, L] (uint8) and t_dead (first frame after which every state is <= -1000; T if never)"""
+    lp = _f32(lp)
+    T, C = lp.shape
+    path = _i32(path)
+    pidx = _i32(pidx)
+    L = path.shape[0]
+    fph = np.empty(T, np.int32)
+    fidx = np.empty(T, np.int32)
+    states = np.empty(T, np.int32)
+    fdp = np.empty(L, np.float32)
+    K = np.empty((T, L), np.uint8)
+    td = ctypes.c_int32(0)
+    rc = lib().ora_viterbi_trace(_p(lp), ctypes.c_long(C), T, C, _p(path), _p(pidx), L, int(band_width),
+                                 int(bool(truly_forced)), int(blank), int(bool(pace_f32)), _p(fph), _p(fidx),
+                                 _p(states), _p(fdp), _p(K), ctypes.byref(td))
+    return rc, fph, fidx, states, fdp, K, int(td.value)
+
+
+def dead_tail_codes(lp, path, band_width, t_from, pace_f32=False):
+    """closed form of the codes of frames [t_from, T) in the dead sentinel regime (bfa_oracle.c: ora_dead_tail_codes)"""
+    lp = _f32(lp)
+    T, C = lp.shape
+    path = _i32(path)
+    L = path.shape[0]
+    K = np.zeros((T, L), np.uint8)
+    rc = lib().ora_dead_tail_codes(_p(lp), ctypes.c_long(C), T, C, _p(path), L, int(band_width), int(bool(pace_f32)),
+                                   int(t_from), _p(K))
+    return rc, K
+
+
+def window_codes(lp, path, band_width, RW):
+    """codes of the full DP from the sliding-window recurrence + the out-of-window closed form (ora_window_codes)"""
+    lp = _f32(lp)
+    T, C = lp.shape
+    path = _i32(path)
+    L = path.shape[0]
+    K = np.zeros((T, L), np.uint8)
+    fdp = np.empty(L, np.float32)
+    mg = ctypes.c_int32(0)
+    rc = lib().ora_window_codes(_p(lp), ctypes.c_long(C), T, C, _p(path), L, int(band_width), int(RW), _p(K), _p(fdp),
+                                ctypes.byref(mg))
+    return rc, K, fdp, int(mg.value)
+
+
+def win_class_for(L, bw):
+    """bfa_types.hpp: win_class_for without the frame limit (states per lane of the narrowest window that holds the band)"""
+    if bw <= 0:
+        return 0
+    r = (L + 63) // 64
+    rfull = next((c for c in (2, 3, 4, 6, 8, 12, 16) if r <= c), 0)
+    for rw in (1, 2, 3, 4, 6, 8):
+        if rfull == 0 or rw >= rfull:
+            break
+        fpw = 16 if rw == 1 else 8 if rw == 2 else 4
+        if 2 * bw + 1 + fpw + 2 + rw + 1 <= 64 * rw:
+            return rw
+    return 0
+
+
 def prepare_emissions(lp, seq, params):
     lp = _f32(lp)
     T, C = lp.shape
