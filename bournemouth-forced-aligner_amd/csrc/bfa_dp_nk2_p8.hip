@@ -1,0 +1,6 @@
+// K1 class kernels of the hot path, width class 2, part 8: the exact-window classes (see BFA_PART in bfa_dp.inc)
+#define BFA_NK 2
+#define BFA_DP3_NFULL 1
+#define BFA_DP3_TAIL 1
+#define BFA_PART 8
+#include "bfa_dp.inc"

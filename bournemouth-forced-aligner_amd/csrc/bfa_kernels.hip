@@ -226,26 +226,36 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
     const int Lmax = 4 * a.Smax + 1;
     unsigned mask = r_class_mask_upto(Lmax);
-    if (p.class_mask & 0xffffu) mask &= p.class_mask; // (flag bits alone are not a class selection)
+    const bool hinted = ((unsigned)p.class_mask & 0x0ff0ffffu) != 0u; // a class selection (flag bits alone are not one)
+    if (hinted) mask &= (unsigned)p.class_mask & 0xffffu;
     const bool seg_possible = !p.simple && p.anchors > 0 && p.sil >= 0 && !(p.class_mask & BFA_HINT_NO_SILENCE_TARGETS);
     const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
     // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
-    unsigned wmask = 0;
+    unsigned wmask = 0, wall = 0;
     if (mode != 2 && (a.C == 67 || a.C == 17) && Lmax > 60) {
         wmask = 0xafu; // Rw in {1,2,3,4,6,8} (bit Rw-1); classes no utterance can use cost one empty launch each
         const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
         for (int rw = 8; rw >= 1; --rw) // drop the classes above the one the longest possible path would take
             if (top > 0 && rw > top) wmask &= ~(1u << (rw - 1));
-        if (p.class_mask & 0xffffu) wmask &= (p.class_mask >> 8);
+        wall = wmask;
+        if (hinted) wmask &= (p.class_mask >> 8);
     }
     // (the window result is exact because emissions are <= 0; a floor above log(1) = 0 would break that argument)
-    if (!(p.min_logp <= 0.0f)) wmask = 0;
+    if (!(p.min_logp <= 0.0f)) { wmask = 0; wall = 0; }
     // Silence-anchored mode: no sliding window.  Only the few utterances whose segmented attempt fails would use it, and
     // the window consumers in the mode's merged K1 kernel cost every PIECE 30 spilled VGPRs (one 256-byte scratch store per
     // item and spilled register: 0.29 GB of DRAM writes per 4096-utterance launch; realtext 1.54 -> 1.49 ms per step).
     if (seg_possible) wmask = 0;
     a.p.win_mask = wmask;
     mask |= wmask << 8;
+    // Exact-window classes (bfa_dp3.inc: DpCoreW<.., EX>): banded standard-mode items the fast window is not tried on -- too
+    // many frames or tokens for a result that only stands above the sentinel -- compute their in-band states only, too,
+    // instead of all L; bit 8: the exact window also reruns the fast windows that end at the sentinel.  Same conditions as
+    // the fast window (its exactness argument needs emissions <= 0 as well).
+    unsigned xmask = 0;
+    if (wall && mode == 0) xmask = (hinted ? (wall & ((unsigned)p.class_mask >> 20)) : wall) | 0x100u;
+    a.p.xwin_mask = xmask;
+    mask |= (xmask & 0xafu) << 20;
     // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
     // class right behind its K1 kernel on that kernel's stream, the window classes after the sentinel reruns, and
     // emits the run-length tuples during the walk -- no K3a launch.
@@ -262,8 +272,9 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         static const int one_max = [] { const char *e = getenv("BFA_ONE_MAX_BATCH"); return e ? atoi(e) : 1024; }(); // (0 switches it off)
         const unsigned hw = (p.class_mask >> 8) & 0xffu;
         const int rw1 = (hw == 1u) ? 1 : (hw == 2u) ? 2 : (hw == 4u) ? 3 : 0;
-        if (fused_k2 && rw1 > 0 && (p.class_mask & 0x7fu) == 0 && (wmask >> (rw1 - 1) & 1u) && a.B <= one_max && Lmax <= 256 &&
+        if (fused_k2 && rw1 > 0 && (p.class_mask & 0x7fu) == 0 && (xmask & 0xafu) == 0 && (wmask >> (rw1 - 1) & 1u) && a.B <= one_max && Lmax <= 256 &&
             a.frame_ph && a.frame_idx) {
+            a.p.xwin_mask = 0; // (k_one reruns its own window failures with the full layout)
             if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
             if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);
             if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
@@ -279,7 +290,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // (silence-anchored mode on the two head widths: the narrow classes are one launch on the caller's stream, bfa_dp3.inc)
     const bool merged_narrow = mode == 1 && (a.C == 67 || a.C == 17);
     const unsigned kmask = merged_narrow ? (mask & ~3u) : mask;
-    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0);
+    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + __builtin_popcount(xmask & 0xafu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0);
     LaunchFan fan;
     fan.main_stream = stream;
     fan.aux = (hipStream_t *)aux_streams;
@@ -289,7 +300,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     fan.used = 0;
     // several K1 kernels side by side: the window items are walked on the window kernels' stream as soon as those are
     // done (with ONE kernel -- the headline batch -- that would only add a launch to the serial chain)
-    a.k2_windows = (per_class_k2 && fan.naux > 0 && wmask != 0) ? 1 : 0;
+    a.k2_windows = (per_class_k2 && fan.naux > 0 && (wmask != 0 || (xmask & 0xafu) != 0)) ? 1 : 0;
     if (Lmax > 1024) { // paths of more than 1024 states can occur: the workgroup-wide kernel takes them
         const int big_grid = a.B < 1024 ? a.B : 1024;
         hipStream_t bs = fan.pick();
@@ -310,10 +321,10 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
     // which of the two walk kernels can find work: narrow (Rw <= 4 / R <= 4, and every non-DP item), wide (Rw 6 / 8, R >= 6,
     // paths beyond 1024 states) -- from the classes that can occur (`mask`) and, for window reruns, the widest path
-    const bool any_wide = (mask & (0x78u | (0xa0u << 8))) != 0 || Lmax > 256;
+    const bool any_wide = (mask & (0x78u | (0xa0u << 8) | (0xa0u << 20))) != 0 || Lmax > 256;
     if (per_class_k2) {
         // window / rerun items, fills, items nobody took: wide only if a window item (or its full-layout rerun) can be
-        const bool rest_wide = (mask & (0xa0u << 8)) != 0 || Lmax > 256; // (also wide items whose K1 class the hint left out: they are reported as BAD_HINT by the wide walk)
+        const bool rest_wide = (mask & ((0xa0u << 8) | (0xa0u << 20))) != 0 || Lmax > 256; // (also wide items whose K1 class the hint left out: they are reported as BAD_HINT by the wide walk)
         bfa_launch_backtrace_sel(&a, a.k2_windows ? K2_REST_NOWIN : K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
         if (!fused_k2) hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     } else {

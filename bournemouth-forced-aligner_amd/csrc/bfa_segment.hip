@@ -357,7 +357,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         if (n <= 0) continue;
         Item it;
         it.kind = ITEM_NONE; it.utt = b; it.row0 = s.a0; it.Ts = n; it.tok0 = s.t0; it.nt = s.t1 - s.t0; it.stride = 0;
-        it.L = 0; it.bw = 0; it.out0 = s.a0; it.nout = n; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.split = 0;
+        it.L = 0; it.bw = 0; it.out0 = s.a0; it.nout = n; it.pad_left = 0; it.final_state = FINAL_NOT_COMPUTED; it.anch_off = -1; it.win = 0; it.split = 0; it.xw = XW_FAST; it.t_tail = 0;
         it.bp_off = bp_off;
         if (s.is_sil) it.kind = ITEM_FILL_SIL;          // :382-397
         else if (it.nt == 0) it.kind = ITEM_FILL_BLANK; // :409-412
@@ -414,7 +414,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         Item it;
         it.kind = (w < T) ? ITEM_FILL_BLANK : ITEM_NONE; it.utt = b; it.row0 = 0; it.Ts = 0; it.tok0 = 0; it.nt = 0;
         it.stride = 0; it.L = 0; it.bw = 0; it.out0 = min(w, T); it.nout = max(0, T - w); it.pad_left = 0;
-        it.final_state = 0; it.anch_off = -1; it.win = 0; it.split = 0; it.bp_off = 0;
+        it.final_state = 0; it.anch_off = -1; it.win = 0; it.split = 0; it.xw = XW_FAST; it.t_tail = 0; it.bp_off = 0;
         while (slot < base + npieces) { if (writer) a.items[slot] = it; ++slot; }
     }
     if (writer) {

@@ -40,7 +40,15 @@ struct Item {
     int64_t bp_off;    // dword offset of this item's backpointer block in the workspace
     int32_t win;       // > 0: K1 used the sliding in-band state window with `win` states per lane (bp: window layout)
     int32_t split;     // 2: K1 split the full layout over two consumer waves (bp: per-frame lane masks, bfa_dp5.inc)
+    // Window items only.  XW_FAST: the fast window consumer (its result stands when the final score is above the sentinel);
+    // XW_EXACT: the EXACT window consumer takes the item -- every window state is computed exactly as in the reference and
+    // the codes of the states outside the window follow from a per-frame side band (see DpCoreW<.., EX>), so the result
+    // stands in every regime; XW_REDO: a fast window ended at the sentinel, the exact consumer reruns the item;
+    // XW_REDONE: that rerun is done (walked with the rest after the join).
+    int32_t xw;
+    int32_t t_tail;    // exact-window items: > 0 = K1 left the serial loop at this frame (the scores were dead): k_dp4x_tail writes the rest
 };
+constexpr int XW_FAST = 0, XW_EXACT = 1, XW_REDO = 2, XW_REDONE = 3;
 
 // one wavefront's candidates for the final-state rule (forced_alignment.py:656-682) when a DP is spread over
 // several wavefronts (k_dp_big, k_dp5): rightmost / best state above the sentinel, best of all, dp[L-1], dp[L-2]
@@ -52,6 +60,7 @@ struct DevParams {
     int32_t blank, sil, anchors, ignore_noise, truly_forced, boost, enforce, simple, max_blanks;
     uint32_t class_mask; // K1 classes to launch (host hint), 0 = derive from the shapes
     uint32_t win_mask;   // sliding-window classes the planner may use (bit Rw-1), set by bfa_launch_align
+    uint32_t xwin_mask;  // exact-window classes (bit Rw-1): banded items the fast window is not tried on (long, many tokens)
     int32_t win_max_tokens; // no window attempt for utterances with more tokens
     int32_t win_max_frames; // ... or more frames
     float min_logp;         // floor of the target columns: float32 log(min_phoneme_prob), forced_alignment.py:70
@@ -100,7 +109,7 @@ struct AlignArgs {
     int32_t xcd_contig;     // K1 (one item per workgroup): slot = xcd_eighth(workgroup id) (BFA_HINT_UNIFORM_LENGTHS)
     int32_t k2_windows;     // launcher: the window items are walked behind the window kernels on their stream (K2_WIN)
 };
-constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
+constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_XWIN = 5, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
 constexpr int K2_NARROW = 64; // | (class bits of the merged narrow full-layout classes << 8): K2_WIN + those classes (k_dp4w_any)
 
 struct ConfArgs {

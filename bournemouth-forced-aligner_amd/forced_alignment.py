@@ -214,7 +214,8 @@ class ViterbiDecoder:
         """Optional host-side hint for bfa_params.class_mask: the K1 kernel classes that occur in this batch,
         from HOST copies of the lengths.  Bits 0-6: full-layout states-per-lane classes {2,3,4,6,8,12,16};
         bits 8-15: sliding-window classes Rw in {1,2,3,4,6,8} at bit 7+Rw (used for standard-mode DPs whose band is narrower than
-        the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`).
+        the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`); bits 20-27: the EXACT window
+        of class Rw at bit 19+Rw (utterances with more frames / tokens than the fast window is tried on).
         `has_sil` says whether any target may contain the silence id (then the segmented mode can create
         shorter DPs, and every full class up to the largest is kept; otherwise bit 16 tells the library to
         skip the silence planning, and a target that does contain it is reported as ITEM_BAD_HINT).  Bit 17 (a speed hint) says the
@@ -250,10 +251,19 @@ class ViterbiDecoder:
                 rw[fits] = r
             max_tok = self.window_max_tokens if self.window_max_tokens else self._WIN_MAX_TOKENS
             max_frm = self.window_max_frames if self.window_max_frames else self._WIN_MAX_FRAMES
-            rw[(bw <= 0) | (T > max_frm) | (S > max_tok) | (ci > 6) | ~is_dp] = 0
+            rw[(bw <= 0) | (ci > 6) | ~is_dp] = 0
+            # too long / too many tokens for the fast window (its result only stands above the sentinel): the EXACT window
+            # of the same class, bits 20-27 (strides >= 3, standard mode only: bfa_plan.inc)
+            exact = (rw > 0) & ((T > max_frm) | (S > max_tok))
+            rx = np.where(exact & (stride >= 3) & (not (has_sil and anchor_pauses and self.silence_anchors > 0)), rw, 0)
+            rw[exact] = 0
+            for r in np.unique(rx[rx > 0]):
+                mask |= 1 << (19 + int(r))
+        else:
+            rx = rw
         for r in np.unique(rw[rw > 0]):
             mask |= 1 << (7 + int(r))                            # (the rare sentinel rerun needs no hint bit)
-        for c in np.unique(ci[is_dp & (rw == 0) & (ci <= 6)]):
+        for c in np.unique(ci[is_dp & (rw == 0) & (rx == 0) & (ci <= 6)]):
             mask |= 1 << int(c)
         if has_sil and anchor_pauses and self.silence_anchors > 0 and not simple and (S > 0).any():
             top = int(np.minimum(np.searchsorted(classes, (4 * S[S > 0] + 1 + 63) // 64), 6).max())

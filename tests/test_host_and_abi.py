@@ -110,11 +110,13 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=67) == NS | 1 << 8
     assert vd.class_mask_hint([600], [20], has_sil=False, n_classes=40) == NS | 0b1       # other widths: generic kernel
     # more than 64 tokens: no window attempt (the path score would usually cross the sentinel) unless the limit is raised
-    assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001
-    assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 5      # R=12
+    # -> the EXACT window of the same class (bits 20-27: Rw at bit 19+Rw), which stands in every regime
+    assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 23) | 0b1  # L=481 -> exact Rw=4
+    assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 25     # L=721, bw=180 -> exact Rw=6
+    assert vd.class_mask_hint([400], [180], has_sil=False, n_classes=67) == NS | 1 << 3      # stride 2 (L=361): no exact window, full layout R=6
     vd.window_max_tokens = 4096
     assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
-    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | 0b10001       # T > 1536: full layout
+    assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 23) | 0b1  # T > 1536: exact Rw=4
     assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 13     # L=721, bw=180 -> 372 states -> Rw=6
     # bit 17 (speed hint): 64 or more utterances with about the same number of frames
     from bournemouth_forced_aligner_amd._lib import HINT_UNIFORM_LENGTHS as UL
