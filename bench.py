@@ -109,10 +109,12 @@ class Ranks:
     def describe(self):
         """[{rank, device, name, ...}] for every rank (gathered), so the line shows which GPUs really took part."""
         if self.dry:
-            me = {"rank": self.rank, "device": "cpu (dry run)", "pid": os.getpid()}
+            me = {"rank": self.rank, "device": "cpu (dry run)", "pid": os.getpid(), "local_rank": self.local_rank,
+                  "would_pin": f"cuda:{self.local_rank}", "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         else:
             pr = torch.cuda.get_device_properties(self.dev)
-            me = {"rank": self.rank, "device": f"cuda:{self.local_rank}", "name": pr.name,
+            me = {"rank": self.rank, "device": f"cuda:{self.local_rank}", "local_rank": self.local_rank,
+                  "current_device": int(torch.cuda.current_device()), "name": pr.name,
                   "gcn_arch": getattr(pr, "gcnArchName", ""), "cus": pr.multi_processor_count,
                   "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")),
                   "hbm_gb": round(pr.total_memory / 2 ** 30, 1), "pid": os.getpid()}

@@ -147,6 +147,26 @@ class PhonemeTimestampAligner:
             lengths[i] = k
         return out, lengths, codes
 
+    def chop_wav(self, wav, start_frame, end_frame):
+        """core.py:288-320, the reference's public single-segment front end (its examples and tests call it): one
+        (channels, samples) clip -> (mono unit-RMS row of wav_len_max samples, valid length, 0), or (None, None, -1 / -2)
+        with the reference's messages.  A one-row call of `_chop_segments`."""
+        rows, lengths, codes = self._chop_segments([wav], [(start_frame, end_frame)])
+        if codes[0] == -1:
+            asked = (end_frame - start_frame) if end_frame != -1 else -1
+            print(f"ERROR: Segment too short: {asked} frames, minimum required is {self.seg_duration_min_samples} frames.")
+            return None, None, -1
+        if codes[0] == -2:
+            print(f"Wav shape is too small: {wav[:, start_frame:end_frame].shape}, start_frame: {start_frame}, end_frame: {end_frame}")
+            return None, None, -2
+        return rows[0], lengths[0], 0
+
+    @staticmethod
+    def _rms_normalize(audio):
+        """core.py:322-328: unit RMS (silence stays silence)."""
+        level = audio.square().mean().sqrt()
+        return audio / level if level > 0 else audio
+
     def _setup_decoders(self):
         """core.py:252-257"""
         self.alignment_utils_g = AlignmentUtils(blank_id=self.blank_group, silence_id=self.silence_group,

@@ -445,6 +445,7 @@ int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int6
     a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = 1; a.p.max_blanks = 10;
     a.p.class_mask = 0; a.p.win_mask = 0; a.p.win_max_tokens = 0; a.p.win_max_frames = 0;
     a.p.min_logp = params->has_min_log_prob ? params->min_log_prob : bfa::MIN_LOGP;
+    if (a.p.min_logp != a.p.min_logp) return fail(h, BFA_ERR_INVALID_ARGUMENT, "min_log_prob is NaN"); // (as in align_core)
     // k_plan also writes seg_count/status: point them at scratch
     a.seg_count = a.uS; a.status = a.umode; a.seg_cap = 1;
     a.seg_count = (int32_t *)a.frame_ph; a.status = (int32_t *)a.frame_idx;

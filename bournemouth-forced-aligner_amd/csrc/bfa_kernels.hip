@@ -50,6 +50,47 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 }
 
 // =================================================================================================
+// k_order : the utterance slots of a mixed-length call by decreasing cost (frames x states per lane), for k_mix: workgroup w
+// of that kernel takes order[w], so the dispatcher starts the longest chains first and fills in with the short ones as
+// workgroups retire.  One workgroup: 1024-bucket counting sort in LDS (the order inside a bucket does not matter).
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_order(AlignArgs a, int32_t *order)
+{
+    __shared__ int cnt[1024];
+    __shared__ int scan[1024];
+    const int tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    const int64_t keymax = (int64_t)a.Tmax * 20 + 1;
+    auto bucket_of = [&](int b) -> int {
+        const Item *it = a.items + b;
+        int64_t key = 0;
+        if (it->kind == ITEM_DP) {
+            const int w = it->win > 0 ? it->win : (it->L <= 1024 ? r_class_for_L(it->L) : 16);
+            key = (int64_t)it->Ts * (4 + w);
+        }
+        int bk = (int)(key * 1023 / keymax);
+        if (bk > 1023) bk = 1023;
+        return 1023 - bk; // descending cost
+    };
+    for (int b = tid; b < a.B; b += 1024) atomicAdd(&cnt[bucket_of(b)], 1);
+    __syncthreads();
+    // exclusive prefix sum over the 1024 buckets (Hillis-Steele, ten rounds)
+    int v = cnt[tid];
+    scan[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = (tid >= off) ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    cnt[tid] = scan[tid] - v; // first slot of the bucket
+    __syncthreads();
+    for (int b = tid; b < a.B; b += 1024) order[atomicAdd(&cnt[bucket_of(b)], 1)] = b;
+}
+
+// =================================================================================================
 // K3a : assort_frames (forced_alignment.py:777-834), one wavefront per utterance
 // =================================================================================================
 __global__ __launch_bounds__(64) void k_assort(AlignArgs a)
@@ -214,6 +255,8 @@ extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, in
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
 extern "C" void bfa_k1_one_nk2(const bfa::AlignArgs *a, int RW, hipStream_t s);
 extern "C" void bfa_k1_one_nk5(const bfa::AlignArgs *a, int RW, hipStream_t s);
+extern "C" void bfa_k1_mix_nk2(const bfa::AlignArgs *a, const int32_t *order, hipStream_t s);
+extern "C" void bfa_k1_mix_nk5(const bfa::AlignArgs *a, const int32_t *order, hipStream_t s);
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
                                 void **aux_streams, void **aux_events, void *fork_event, int naux)
@@ -253,7 +296,16 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // instead of all L; bit 8: the exact window also reruns the fast windows that end at the sentinel.  Same conditions as
     // the fast window (its exactness argument needs emissions <= 0 as well).
     unsigned xmask = 0;
-    if (wall && mode == 0) xmask = (hinted ? (wall & ((unsigned)p.class_mask >> 20)) : wall) | 0x100u;
+    if (wall && mode == 0) xmask = (hinted ? (wall & ((unsigned)p.class_mask >> 20)) : wall) | XWIN_REDO;
+    // Mixed-length calls (the caller has not promised uniform lengths): ONE kernel aligns and walks every utterance of the
+    // narrow classes (bfa_dp4.inc: k_mix) -- the exact window for every stride >= 3 window item of the classes Rw <= 4 (a hinted
+    // fast-window class stands for its exact twin), the full layout R <= 4 -- in longest-first order (k_order).
+    const bool use_mix = mode == 0 && !seg_possible && (a.C == 67 || a.C == 17) && wall != 0 && a.B >= MIX_MIN_BATCH &&
+                         !(p.class_mask & BFA_HINT_UNIFORM_LENGTHS) && a.frame_ph && a.frame_idx;
+    if (use_mix) {
+        const unsigned narrow_x = hinted ? (wall & (((unsigned)p.class_mask >> 20) | ((unsigned)p.class_mask >> 8)) & 0xfu) : (wall & 0xfu);
+        xmask |= narrow_x | XWIN_MIX;
+    }
     a.p.xwin_mask = xmask;
     mask |= (xmask & 0xafu) << 20;
     // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
@@ -286,11 +338,17 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+    if (use_mix) {
+        // (`cand` is the candidate list of the silence-anchored mode, which this call cannot enter: it holds the order)
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a, a.cand);
+        // the narrow classes are k_mix's: the class kernels below only see what it does not take
+        mask &= ~(7u | (0xfu << 20));
+    }
     // one kernel per class; with more than one class to launch they run side by side on the auxiliary streams
     // (silence-anchored mode on the two head widths: the narrow classes are one launch on the caller's stream, bfa_dp3.inc)
     const bool merged_narrow = mode == 1 && (a.C == 67 || a.C == 17);
     const unsigned kmask = merged_narrow ? (mask & ~3u) : mask;
-    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + __builtin_popcount(xmask & 0xafu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0);
+    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + __builtin_popcount(xmask & 0xafu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0) + (use_mix ? 1 : 0);
     LaunchFan fan;
     fan.main_stream = stream;
     fan.aux = (hipStream_t *)aux_streams;
@@ -312,6 +370,9 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, &fan);
+    if (use_mix) { // on the caller's stream, after the forks (the other classes' kernels run beside it)
+        if (a.C == 67) bfa_k1_mix_nk5(&a, a.cand, stream); else bfa_k1_mix_nk2(&a, a.cand, stream);
+    }
     fan.join();
     const bool redo_done = a.k2_windows && (a.C == 67 || a.C == 17); // (launched behind the window kernels on their stream, bfa_dp3.inc)
     if (redo_done) { /* nothing */ }

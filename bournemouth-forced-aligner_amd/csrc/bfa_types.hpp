@@ -19,7 +19,8 @@ enum ItemKind : int32_t {
     ITEM_DP = 1,          // banded Viterbi over rows [row0,row0+Ts), writes frames [out0,out0+nout)
     ITEM_FILL_BLANK = 2,  // blank / -1
     ITEM_FILL_PROP = 3,   // proportional assignment forced_alignment.py:170-172
-    ITEM_FILL_SIL = 4     // silence segment, forced_alignment.py:382-397
+    ITEM_FILL_SIL = 4,    // silence segment, forced_alignment.py:382-397
+    ITEM_DONE = 5         // k_mix has aligned AND walked the utterance (nothing left for the walk kernels)
 };
 
 struct Item {
@@ -49,6 +50,8 @@ struct Item {
     int32_t t_tail;    // exact-window items: > 0 = K1 left the serial loop at this frame (the scores were dead): k_dp4x_tail writes the rest
 };
 constexpr int XW_FAST = 0, XW_EXACT = 1, XW_REDO = 2, XW_REDONE = 3;
+constexpr uint32_t XWIN_REDO = 0x100u, XWIN_MIX = 0x200u;
+constexpr int MIX_MIN_BATCH = 64; // smaller calls keep the per-class kernels (a lone long utterance: its dead tail runs segment-parallel there)
 
 // one wavefront's candidates for the final-state rule (forced_alignment.py:656-682) when a DP is spread over
 // several wavefronts (k_dp_big, k_dp5): rightmost / best state above the sentinel, best of all, dp[L-1], dp[L-2]
@@ -60,7 +63,9 @@ struct DevParams {
     int32_t blank, sil, anchors, ignore_noise, truly_forced, boost, enforce, simple, max_blanks;
     uint32_t class_mask; // K1 classes to launch (host hint), 0 = derive from the shapes
     uint32_t win_mask;   // sliding-window classes the planner may use (bit Rw-1), set by bfa_launch_align
-    uint32_t xwin_mask;  // exact-window classes (bit Rw-1): banded items the fast window is not tried on (long, many tokens)
+    uint32_t xwin_mask;  // exact-window classes (bit Rw-1): banded items the fast window is not tried on (long, many tokens);
+                         // bit 8: the exact window reruns fast windows that ended at the sentinel; bit 9 (XWIN_MIX): a mixed-length
+                         // call -- every window item with stride >= 3 of these classes is an exact-window item (k_mix takes them)
     int32_t win_max_tokens; // no window attempt for utterances with more tokens
     int32_t win_max_frames; // ... or more frames
     float min_logp;         // floor of the target columns: float32 log(min_phoneme_prob), forced_alignment.py:70

@@ -225,6 +225,10 @@ class ViterbiDecoder:
         if T.size == 0:
             return 0
         window_ok = (n_classes in (67, 17)) and boost_targets and enforce_minimum and not simple
+        # a floor above log(1) = 0 (min_phoneme_prob > 1) breaks the window's exactness argument: the library then runs
+        # every item with the full layout (bfa_launch_align), so the hint must name the full classes
+        if window_ok and not (float(torch.log(torch.tensor(self.min_phoneme_prob, dtype=torch.float32))) <= 0.0):
+            window_ok = False
         classes = np.array((2, 3, 4, 6, 8, 12, 16))
         if simple:  # forced_alignment.py:963-968 (float32 compares); S = 0 still runs a DP over the single blank state
             f32 = np.float32
@@ -255,7 +259,12 @@ class ViterbiDecoder:
             # too long / too many tokens for the fast window (its result only stands above the sentinel): the EXACT window
             # of the same class, bits 20-27 (strides >= 3, standard mode only: bfa_plan.inc)
             exact = (rw > 0) & ((T > max_frm) | (S > max_tok))
-            rx = np.where(exact & (stride >= 3) & (not (has_sil and anchor_pauses and self.silence_anchors > 0)), rw, 0)
+            no_seg = not (has_sil and anchor_pauses and self.silence_anchors > 0)
+            # a mixed-length call (bfa_launch_align: no promise of uniform lengths, 64 utterances or more): every stride >= 3
+            # window item of the classes Rw <= 4 is an exact-window item (k_mix aligns and walks it in one workgroup)
+            if no_seg and T.size >= _lib.MIX_MIN_BATCH and not self._uniform(T):
+                exact = exact | ((rw > 0) & (rw <= 4) & (stride >= 3))
+            rx = np.where(exact & (stride >= 3) & no_seg, rw, 0)
             rw[exact] = 0
             for r in np.unique(rx[rx > 0]):
                 mask |= 1 << (19 + int(r))
@@ -270,9 +279,13 @@ class ViterbiDecoder:
             mask |= (1 << (top + 1)) - 1                         # speech segments can be any shorter class
         if not has_sil and mask:
             mask |= _lib.HINT_NO_SILENCE_TARGETS  # the silence-anchored planning kernels are not launched
-        if mask and T.size >= 64 and int(T.max() - T.min()) * 8 <= int(T.max()):
+        if mask and self._uniform(T):
             mask |= _lib.HINT_UNIFORM_LENGTHS     # about the same number of frames everywhere: one contiguous eighth of the batch per XCD
         return mask
+
+    @staticmethod
+    def _uniform(T):
+        return T.size >= 64 and int(T.max() - T.min()) * 8 <= int(T.max())
 
     def _prepare_call(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
                       anchor_pauses=True, simple=False, seg_cap=None, max_blanks=10, class_mask=0):
@@ -530,5 +543,6 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
     for c in calls:
         res = ViterbiDecoder._result(c)
         res.conf, res.conf_status = c.get("conf"), c.get("cstat")
+        res.postprocessed = post is not None  # coverage / soft boundaries already ran in place (they are not idempotent)
         out.append((res, c["stats"]))
     return out

@@ -122,7 +122,12 @@ def test_class_mask_hint():
     from bournemouth_forced_aligner_amd._lib import HINT_UNIFORM_LENGTHS as UL
     assert vd.class_mask_hint([1000] * 64, [40] * 64, has_sil=False, n_classes=67) == NS | UL | 1 << 9
     assert vd.class_mask_hint([1000] * 63 + [900], [40] * 64, has_sil=False, n_classes=67) == NS | UL | 1 << 9
-    assert vd.class_mask_hint([1000] * 63 + [500], [40] * 63 + [20], has_sil=False, n_classes=67) == NS | 1 << 9 | 1 << 8
+    # 64 or more utterances whose lengths differ: the mixed-length path (k_mix) -- the stride >= 3 window items of the classes
+    # Rw <= 4 are exact-window items (bits 20-23); stride-2 paths keep the fast window; fewer than 64: as before
+    assert vd.class_mask_hint([1000] * 63 + [500], [40] * 63 + [20], has_sil=False, n_classes=67) == NS | 1 << 21 | 1 << 20
+    assert vd.class_mask_hint([1000] * 62 + [500], [40] * 62 + [20], has_sil=False, n_classes=67) == NS | 1 << 9 | 1 << 8
+    assert vd.class_mask_hint([1000] * 63 + [300], [40] * 63 + [100], has_sil=False, n_classes=67) == NS | 1 << 21 | 1 << 9  # stride 2, L=201: fast Rw=2
+    assert vd.class_mask_hint([1000] * 63 + [500], [40] * 63 + [20], has_sil=True, n_classes=67) == 0b11 | 1 << 9 | 1 << 8  # SIL possible: no mixed path (the library drops the window bits in that mode)
     assert vd.class_mask_hint([900], [187], has_sil=False, n_classes=67) == NS | 1 << 15     # L=749, bw=187 -> 390 states -> Rw=8
     assert vd.class_mask_hint([1200], [250], has_sil=False, n_classes=67) == NS | 1 << 6     # L=1001, bw=250: 516 states > 512 -> full R=16
     assert vd.class_mask_hint([], [], has_sil=False) == 0
@@ -429,3 +434,110 @@ def test_headline_k1_keeps_eight_waves_per_simd():
         assert key, sorted(res)
         vgpr, vspill, occ, lds = res[key[0]]
         assert vgpr <= 64 and vspill == 0 and occ == 8 and lds <= 10240, (rw, res[key[0]])
+
+
+def test_chop_wav_is_the_reference_single_segment_front_end(capsys):
+    """core.py:288-328: the public chop_wav / _rms_normalize the reference's examples and tests call."""
+    from bournemouth_forced_aligner_amd import PhonemeTimestampAligner
+    al = PhonemeTimestampAligner(preset=None, device="cpu")
+    g = torch.Generator().manual_seed(5)
+    wav = torch.randn(2, 40000, generator=g)
+    row, n, code = al.chop_wav(wav, 1000, 9000)
+    assert code == 0 and n == 8000 and row.shape == (al.wav_len_max,)
+    mono = wav[:, 1000:9000].mean(dim=0)
+    want = mono / mono.square().mean().sqrt()
+    assert torch.equal(row[:n], want) and float(row[n:].abs().max()) == 0.0
+    assert torch.equal(al._rms_normalize(mono), want)
+    assert torch.equal(al._rms_normalize(torch.zeros(16)), torch.zeros(16))
+    # longer than the model's window: cut
+    long = torch.randn(1, al.wav_len_max + 500, generator=g)
+    row, n, code = al.chop_wav(long, 0, al.wav_len_max + 500)
+    assert code == 0 and n == al.wav_len_max
+    # too short a request (also end = -1), and a clip that ends early: the reference's codes and messages
+    assert al.chop_wav(wav, 0, 100) == (None, None, -1)
+    assert al.chop_wav(wav, 0, -1) == (None, None, -1)
+    assert "ERROR: Segment too short: -1 frames, minimum required is %d frames." % al.seg_duration_min_samples in capsys.readouterr().out
+    assert al.chop_wav(wav, 39990, 45000) == (None, None, -2)
+    assert "Wav shape is too small: torch.Size([2, 10]), start_frame: 39990, end_frame: 45000" in capsys.readouterr().out
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refload
+    if refload.available():   # live: the reference's own method on the same clips
+        ref = refload.core_aligner()
+        for lo, hi in ((1000, 9000), (0, 100), (0, -1), (39990, 45000), (0, 40000)):
+            a, b = al.chop_wav(wav, lo, hi), ref.chop_wav(wav, lo, hi)
+            assert a[1:] == b[1:]
+            assert (a[0] is None and b[0] is None) or torch.equal(a[0], b[0])
+        capsys.readouterr()
+
+
+def test_bench_gpus_8_dry_run_c4_eight_ranks_agree_and_gather():
+    """The first 8-GPU run must not be the first time the code sees 8 ranks: `bench.py --gpus 8 --config c4`
+    becomes eight processes (gloo here), each pinned to the device of its LOCAL_RANK, that agree on the LPT partition of the
+    fixed batch, and the packed gather puts every utterance's record where it belongs."""
+    out = _bench_json(["--gpus", "8", "--dry-run", "--config", "c4", "--global-batch", "4096"], timeout=900)
+    assert out["dry_run"] and out["n_gpus"] == 8
+    rk = out["ranks"]
+    assert [r["rank"] for r in rk] == list(range(8)) and len({r["pid"] for r in rk}) == 8
+    assert [r["local_rank"] for r in rk] == list(range(8)) and [r["would_pin"] for r in rk] == [f"cuda:{i}" for i in range(8)]
+    assert all(r["ipc_mode_legacy"] == "0" for r in rk)  # dmabuf IPC: RCCL needs it on this driver
+    assert out["shard_agree"] and out["gather_ok"]
+    assert sum(out["shard_sizes"]) == 4096 and min(out["shard_sizes"]) > 0 and out["load_imbalance_max_over_mean"] < 1.01
+    # fewer utterances than ranks: empty shards take part in the gather
+    tiny = _bench_json(["--gpus", "8", "--dry-run", "--config", "c4", "--global-batch", "5"], timeout=900)
+    assert tiny["n_gpus"] == 8 and sorted(tiny["shard_sizes"]) == [0, 0, 0, 1, 1, 1, 1, 1] and tiny["gather_ok"]
+
+
+def _gloo_worker8(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from bournemouth_forced_aligner_amd.sharding import gather_results
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # uneven shards by hand: rank r owns r utterances (rank 0 -- the destination -- owns none) with capacity 3 + 2 r
+    owner = np.concatenate([np.full(r, r) for r in range(world)])
+    n = len(owner)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(n)                      # global position of the k-th owned utterance
+    capmax = 3 + 2 * (world - 1)
+    segs = rng.integers(0, 900, size=(n, capmax, 4)).astype(np.int32)
+    conf = rng.random((n, capmax)).astype(np.float32)
+    mine = perm[owner == rank]
+    cap = 3 + 2 * rank
+    cnt = np.minimum(rng.integers(0, capmax + 1, size=n), 3 + 2 * owner[np.argsort(perm)]).astype(np.int32)  # count <= owner's capacity
+    out = gather_results(torch.from_numpy(segs[mine][:, :cap]), torch.from_numpy(cnt[mine]), torch.from_numpy(conf[mine][:, :cap]),
+                         torch.from_numpy(mine.astype(np.int64)), n, dst=0)
+    if rank == 0:
+        gs, gc, gf = out
+        ok = gs.shape == (n, capmax, 4)
+        for i in range(n):
+            c = int(cnt[i])
+            ok &= int(gc[i]) == c and bool((gs[i, :c].numpy() == segs[i, :c]).all()) and bool((gf[i, :c].numpy() == conf[i, :c]).all())
+        open(os.path.join(tmp, "ok8"), "w").write("1" if ok else "0")
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_gather_with_an_empty_shard_and_unequal_capacities(tmp_path):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert open(os.path.join(str(tmp_path), "ok8")).read() == "1"
+
+
+def test_relaunch_under_torchrun_command_and_environment(monkeypatch):
+    """`python bench.py --gpus N` re-executes itself under torch.distributed.run: one rank per GPU, rendezvous on 127.0.0.1,
+    and the environment multi-process GPU work needs on this driver (dmabuf IPC); the library needs no queue setting."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert bench.relaunch_under_torchrun(8, ["--gpus", "8", "--config", "c4"]) == 0
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--config", "c4"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "GPU_MAX_HW_QUEUES" not in env
