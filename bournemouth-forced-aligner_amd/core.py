@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .coverage import ensure_target_coverage
-from .forced_alignment import AlignmentUtils, align_heads, rows_as_tuple_lists
+from .forced_alignment import AlignmentUtils, LazyRowLists, align_heads, rows_as_tuple_lists
 from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
 
 # one row of extract_timestamps_from_segment_batch's result (core.py:939-956)
@@ -323,7 +323,7 @@ class PhonemeTimestampAligner:
         for k, name in enumerate(("id", "start", "end", "idx")):
             rec[name] = picked[:, k]
         rec["est"], rec["conf"], rec["start_ms"], rec["end_ms"] = est[valid], cf[:, :cap][valid], sms[valid], ems[valid]
-        return rows_as_tuple_lists(rec, ncl)
+        return LazyRowLists(rec, ncl)
 
     def extract_timestamps_from_segment_batch(self, wavs, wav_lens, phoneme_sequences, start_offset_times=0,
                                               group_sequences=None, extract_embeddings=False, do_groups=True,

@@ -50,44 +50,29 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 }
 
 // =================================================================================================
-// k_order : the utterance slots of a mixed-length call by decreasing cost (frames x states per lane), for k_mix: workgroup w
-// of that kernel takes order[w], so the dispatcher starts the longest chains first and fills in with the short ones as
-// workgroups retire.  One workgroup: 1024-bucket counting sort in LDS (the order inside a bucket does not matter).
+// k_order : the utterance slots of a mixed-length call by decreasing cost, for k_mix: workgroup w of that kernel takes
+// order[w], so the dispatcher starts the longest chains first and fills in with the short ones as workgroups retire.
+// One workgroup: counting sort over the 256 cost buckets k_plan left in mix_key (the order inside a bucket does not matter).
 // =================================================================================================
-__global__ __launch_bounds__(1024) void k_order(AlignArgs a, int32_t *order)
+__global__ __launch_bounds__(1024) void k_order(AlignArgs a)
 {
-    __shared__ int cnt[1024];
-    __shared__ int scan[1024];
+    __shared__ int cnt[256];
     const int tid = threadIdx.x;
-    cnt[tid] = 0;
+    if (tid < 256) cnt[tid] = 0;
     __syncthreads();
-    const int64_t keymax = (int64_t)a.Tmax * 20 + 1;
-    auto bucket_of = [&](int b) -> int {
-        const Item *it = a.items + b;
-        int64_t key = 0;
-        if (it->kind == ITEM_DP) {
-            const int w = it->win > 0 ? it->win : (it->L <= 1024 ? r_class_for_L(it->L) : 16);
-            key = (int64_t)it->Ts * (4 + w);
-        }
-        int bk = (int)(key * 1023 / keymax);
-        if (bk > 1023) bk = 1023;
-        return 1023 - bk; // descending cost
-    };
-    for (int b = tid; b < a.B; b += 1024) atomicAdd(&cnt[bucket_of(b)], 1);
+    for (int b = tid; b < a.B; b += 1024) atomicAdd(&cnt[a.mix_key[b]], 1);
     __syncthreads();
-    // exclusive prefix sum over the 1024 buckets (Hillis-Steele, ten rounds)
-    int v = cnt[tid];
-    scan[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int add = (tid >= off) ? scan[tid - off] : 0;
-        __syncthreads();
-        scan[tid] += add;
-        __syncthreads();
+    if (tid < 64) { // exclusive prefix sum over the buckets: four per lane, then a wave scan
+        const int c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+        const int mine = c0 + c1 + c2 + c3;
+        int inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (tid >= off) inc += o; }
+        const int base = inc - mine;
+        cnt[4 * tid] = base; cnt[4 * tid + 1] = base + c0; cnt[4 * tid + 2] = base + c0 + c1; cnt[4 * tid + 3] = base + c0 + c1 + c2;
     }
-    cnt[tid] = scan[tid] - v; // first slot of the bucket
     __syncthreads();
-    for (int b = tid; b < a.B; b += 1024) order[atomicAdd(&cnt[bucket_of(b)], 1)] = b;
+    for (int b = tid; b < a.B; b += 1024) a.mix_order[atomicAdd(&cnt[a.mix_key[b]], 1)] = b;
 }
 
 // =================================================================================================
@@ -339,8 +324,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
     if (use_mix) {
-        // (`cand` is the candidate list of the silence-anchored mode, which this call cannot enter: it holds the order)
-        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a, a.cand);
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
         // the narrow classes are k_mix's: the class kernels below only see what it does not take
         mask &= ~(7u | (0xfu << 20));
     }
@@ -371,7 +355,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, &fan);
     if (use_mix) { // on the caller's stream, after the forks (the other classes' kernels run beside it)
-        if (a.C == 67) bfa_k1_mix_nk5(&a, a.cand, stream); else bfa_k1_mix_nk2(&a, a.cand, stream);
+        if (a.C == 67) bfa_k1_mix_nk5(&a, a.mix_order, stream); else bfa_k1_mix_nk2(&a, a.mix_order, stream);
     }
     fan.join();
     const bool redo_done = a.k2_windows && (a.C == 67 || a.C == 17); // (launched behind the window kernels on their stream, bfa_dp3.inc)

@@ -113,6 +113,8 @@ struct AlignArgs {
     int32_t k2_per_class;   // launcher: one K2 launch per full-layout class behind its K1 kernel(s), K2_REST after the join
     int32_t xcd_contig;     // K1 (one item per workgroup): slot = xcd_eighth(workgroup id) (BFA_HINT_UNIFORM_LENGTHS)
     int32_t k2_windows;     // launcher: the window items are walked behind the window kernels on their stream (K2_WIN)
+    uint8_t *mix_key;       // [B] mixed-length calls (DevParams::xwin_mask & XWIN_MIX): 255 - cost bucket of the utterance (k_plan)
+    int32_t *mix_order;     // [B] ... the utterance slots by decreasing cost (k_order), the work list of k_mix
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_XWIN = 5, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
 constexpr int K2_NARROW = 64; // | (class bits of the merged narrow full-layout classes << 8): K2_WIN + those classes (k_dp4w_any)
