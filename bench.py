@@ -255,11 +255,20 @@ def headline_main(args, rk):
     counter = [0]
     last = [None]
 
+    # The reference never aligns without scoring (core.py:902-937: decode_alignments, then _calculate_confidences of the
+    # aligned tuples): a step is K1 (forward pass) + K2 (walk, tuples) + K3 (confidence pass) on the batch's stream, and
+    # `value` counts aligned AND scored frames.  --no-confidences times K1 + K2 only; the default run reports that figure
+    # too (`alignment_only`, a second set of windows).
+    with_conf = [not args.no_confidences]
+
     def step(i):
         lp, tk = bufs[i % nbuf]
         if inflight <= 1:
-            return au.decode_alignments_device(lp, tk, T_len, S_len, class_mask=hint)
-        return bif.submit(lp, tk, T_len, S_len, class_mask=hint)
+            r = au.decode_alignments_device(lp, tk, T_len, S_len, class_mask=hint)
+            if with_conf[0]:
+                r.conf, r.conf_status = calculate_confidences_batch(lp, r.segs, r.seg_count, T_rows=T_len)
+            return r
+        return bif.submit(lp, tk, T_len, S_len, confidences=with_conf[0], class_mask=hint)
 
     def run_steps(n):
         for _ in range(n):
@@ -301,6 +310,17 @@ def headline_main(args, rk):
     win_t, issue_t = _timed_windows(rk, run_steps, K, n_windows)
     check_status(last[0])
     res = last[0]
+    if with_conf[0]:
+        assert int((res.conf_status != 0).sum().item()) == 0, "the confidence pass reported an error on the bench workload"
+    # ---- the same windows without the confidence pass (K1 + K2 only: what rounds 1-3 reported as `value`)
+    only_ms = None
+    if with_conf[0]:
+        with_conf[0] = False
+        run_steps(max(4, inflight))
+        torch.cuda.synchronize()
+        only_t, _ = _timed_windows(rk, run_steps, K, n_windows)
+        only_ms = float(np.sum(only_t)) / (K * n_windows) * 1e3
+        with_conf[0] = True
     # ---- one more window of K steps, not part of `value`, with K1 of every step bracketed by HIP events on its launch
     # stream: how long a launch shares the machine with the others in flight, and for how long any K1 is running
     for h in hs:
@@ -380,6 +400,10 @@ def headline_main(args, rk):
     L = 4 * S + 1
     bytes_per_frame = 4 * C + (L + 3) // 4 + 8
     alg_bytes = frames_per_step * bytes_per_frame
+    # the confidence pass reads ONE float per frame a tuple covers -- a 64-byte DRAM sector each -- and writes a float per tuple
+    covered = int((res.segs[:, :, 2] - res.segs[:, :, 1]).clamp(min=0).mul(
+        torch.arange(res.segs.shape[1], device=dev).unsqueeze(0) < res.seg_count.unsqueeze(1)).sum().item())
+    conf_bytes = 64 * covered + 4 * int(res.seg_count.sum().item()) if not args.no_confidences else 0
     value = world * frames_per_step * total_steps / elapsed
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if nk else None
     busy_per_launch = busy_ms / len(spans) if spans else None
@@ -438,7 +462,11 @@ def headline_main(args, rk):
                          "kernel_ms_per_buffer": [float(np.mean(k1_alone[j::nbuf])) for j in range(nbuf)] if nk else None,
                          "kernel_ms_per_buffer_what": "the kernel leg cycles through the resident batches; K1 takes 0.32 or 0.34 ms depending on where a batch physically lives (profiles/r03_placement.txt)",
                          "kernel_leg_ms_per_step": leg_ms,
-                         "whole_step_frac": alg_bytes / (elapsed / total_steps) / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_frac": (alg_bytes + conf_bytes) / (elapsed / total_steps) / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_what": "K1 + K2 + K3 of a step (" + ("with" if not args.no_confidences else "without") +
+                                            " the confidence pass): algorithmic bytes of K1 plus one 64-byte sector per frame a "
+                                            "tuple covers / ms_per_step",
+                         "confidence_pass_algorithmic_bytes": conf_bytes,
                          "in_flight": {"what": f"K1 brackets of one more window of {K} steps run after the reported ones (the "
                                                "reported windows carry no instrumentation): with several batches in flight "
                                                "the launches overlap and share the machine (duration > busy time per launch)",
@@ -449,6 +477,10 @@ def headline_main(args, rk):
                                        if busy_per_launch else None}},
             "cpu_baseline": cpu,
             "reference_cpu_baseline": _reference_cpu_record(),
+            "step": "K1 + K2 + K3: alignment, walk / tuples, confidence pass (core.py:902-937)" if not args.no_confidences
+                    else "K1 + K2: alignment, walk / tuples (--no-confidences)",
+            "alignment_only": ({"what": "the same windows with K1 + K2 only (no confidence pass): the `value` of rounds 1-3",
+                                "ms_per_step": only_ms, "value": world * frames_per_step / (only_ms * 1e-3)} if only_ms else None),
             "confidence_pass_ms": conf_ms,
             "gather_ms": gather_ms,
             "ranks": ranks,
@@ -1034,6 +1066,8 @@ def main():
                          "(default: 3 for the headline, 1 for --config c4)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="utterances timed on the host oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-confidences", action="store_true",
+                    help="headline: time K1 + K2 only (by default a step also runs the confidence pass of the aligned tuples)")
     ap.add_argument("--no-window", action="store_true", help="A/B: full state layout instead of the sliding window")
     ap.add_argument("--win-frames", type=int, default=0, help="A/B: window frame limit, 0 = default")
     ap.add_argument("--win-tokens", type=int, default=0, help="A/B: window token limit, 0 = default")

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_log_softmax(const float *in, int64_t ld
         float x[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) x[k] = (valid & (1u << k)) ? in[row * ld_in + 16 * k + j] : 0.0f;
-        softmax16<NK>(x, valid);
+        softmax16<NK>(x, valid, nullptr, nullptr, C < 16 ? C : 0);
         if (live) {
 #pragma unroll
             for (int k = 0; k < NK; ++k)
@@ -306,7 +306,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
     {
-        static const int one_max = [] { const char *e = getenv("BFA_ONE_MAX_BATCH"); return e ? atoi(e) : 1024; }(); // (0 switches it off)
+        constexpr int one_max = ONE_MAX_BATCH;
         const unsigned hw = (p.class_mask >> 8) & 0xffu;
         const int rw1 = (hw == 1u) ? 1 : (hw == 2u) ? 2 : (hw == 4u) ? 3 : 0;
         if (fused_k2 && rw1 > 0 && (p.class_mask & 0x7fu) == 0 && (xmask & 0xafu) == 0 && (wmask >> (rw1 - 1) & 1u) && a.B <= one_max && Lmax <= 256 &&
@@ -373,8 +373,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         bfa_launch_backtrace_sel(&a, a.k2_windows ? K2_REST_NOWIN : K2_REST, fused_k2 ? 1 : 0, dp_grid, stream, rest_wide ? 3 : 1);
         if (!fused_k2) hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     } else {
-        static const int k2_env = [] { const char *e = getenv("BFA_K2_GRID"); return e ? atoi(e) : 0; }(); // (measurement switch)
-        bfa_launch_backtrace(&a, k2_env > 0 ? k2_env : dp_grid, stream, any_wide ? 3 : 1);
+        bfa_launch_backtrace(&a, dp_grid, stream, any_wide ? 3 : 1);
         hipLaunchKernelGGL(k_assort, dim3(a.B < 65536 ? a.B : 65536), dim3(64), 0, stream, a);
     }
     return (int)hipGetLastError();

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_silprob(AlignArgs a)
             float x[NK];
 #pragma unroll
             for (int k = 0; k < NK; ++k) x[k] = lp[(int64_t)row * a.strideT + min(16 * k + j, a.C - 1)];
-            if (a.row_stats) softmax16<NK>(x, rl.valid); // raw logits in
+            if (a.row_stats) softmax16<NK>(x, rl.valid, nullptr, nullptr, rl.narrowC); // raw logits in
             boost_floor<NK>(x, rl, p.boost != 0, p.enforce != 0, p.min_logp);
             float v = 0.0f;
 #pragma unroll

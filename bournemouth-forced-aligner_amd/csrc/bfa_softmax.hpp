@@ -13,12 +13,13 @@ struct RowLane {
     uint32_t valid; // bit k : column 16k+j exists
     uint32_t tmask; // bit k : column 16k+j is a boosted / floored target
     int blank_k;    // k such that column 16k+j is the blank column, or -1
+    int narrowC;    // C when C < 16 (fewer columns than one host vector: another summation order, see softmax16), else 0
 };
 
 __device__ __forceinline__ RowLane make_rowlane(int nk, int j, int C, int blank, const uint32_t *um)
 {
     RowLane rl;
-    rl.valid = 0; rl.tmask = 0; rl.blank_k = -1;
+    rl.valid = 0; rl.tmask = 0; rl.blank_k = -1; rl.narrowC = (C < 16) ? C : 0;
     for (int k = 0; k < nk; ++k) {
         const int c = 16 * k + j;
         if (c < C) {
@@ -30,8 +31,13 @@ __device__ __forceinline__ RowLane make_rowlane(int nk, int j, int C, int blank,
     return rl;
 }
 
+// narrowC = C for rows of fewer than sixteen columns (0 otherwise): the host then adds the C exponentials one after the other
+// (a partial vector is reduced element by element: ((e0 + e1) + e2) + ...), not in sixteen accumulators with a butterfly;
+// pinned by tests/golden/narrow_cases.npz (reference outputs for C = 3..15).  The lanes j >= C of a row hold copies of
+// column C - 1 (clamped loads), which the maximum does not mind and the sequential sum never reads.
 template <int NK>
-__device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid, float *mx_out = nullptr, float *ls_out = nullptr)
+__device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid, float *mx_out = nullptr, float *ls_out = nullptr,
+                                          int narrowC = 0)
 {
     float mx = x[0];
 #pragma unroll
@@ -46,7 +52,13 @@ __device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid, float 
         if (k == 0) acc = e;
         else acc = (valid & (1u << k)) ? (acc + e) : acc;
     }
-    const float ls = logf_u10(row16_butterfly_add(acc));
+    float total;
+    if (narrowC > 0) { // (wave-uniform)
+        const int row0 = (int)(threadIdx.x & 63) & ~15;
+        total = __shfl(acc, row0);
+        for (int c = 1; c < narrowC; ++c) total = total + __shfl(acc, row0 + c);
+    } else total = row16_butterfly_add(acc);
+    const float ls = logf_u10(total);
 #pragma unroll
     for (int k = 0; k < NK; ++k) x[k] = x[k] - ls;
     if (mx_out) { *mx_out = mx; *ls_out = ls; }
@@ -64,7 +76,7 @@ __device__ __forceinline__ void anchor_rows(float (&x)[NK], const RowLane &rl, i
         float y[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) y[k] = (k == rl.blank_k) ? x[k] + 5.0f : x[k];
-        softmax16<NK>(y, rl.valid);
+        softmax16<NK>(y, rl.valid, nullptr, nullptr, rl.narrowC);
         if (i < cnt) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) x[k] = y[k];
@@ -79,7 +91,7 @@ __device__ __forceinline__ void boost_floor(float (&x)[NK], const RowLane &rl, b
     if (boost) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) x[k] = (rl.tmask & (1u << k)) ? (x[k] + 5.0f) : x[k];
-        softmax16<NK>(x, rl.valid);
+        softmax16<NK>(x, rl.valid, nullptr, nullptr, rl.narrowC);
     }
     if (enforce) {
 #pragma unroll

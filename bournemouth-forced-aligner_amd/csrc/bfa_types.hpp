@@ -51,6 +51,7 @@ struct Item {
 };
 constexpr int XW_FAST = 0, XW_EXACT = 1, XW_REDO = 2, XW_REDONE = 3;
 constexpr uint32_t XWIN_REDO = 0x100u, XWIN_MIX = 0x200u;
+constexpr int ONE_MAX_BATCH = 1024; // largest single-class call that takes the one-kernel path (k_one; 8192: 0.62 ms against 0.32 + 0.06 for the headline batch)
 constexpr int MIX_MIN_BATCH = 64; // smaller calls keep the per-class kernels (a lone long utterance: its dead tail runs segment-parallel there)
 
 // one wavefront's candidates for the final-state rule (forced_alignment.py:656-682) when a DP is spread over
@@ -183,31 +184,17 @@ __host__ __device__ inline int xcd_eighth(int w, int n)
     return x * q + (x < r ? x : r) + (w >> 3);
 }
 
-// band / window changes as cold branches (laid out off the straight path: the common frame falls through): A/B switch,
-// measured slower for the headline K1 (0.321 -> 0.341 ms) and without effect on a lone chain, so off
-#ifndef BFA_COLD_BAND
-#define BFA_COLD_BAND 0
-#endif
-#if BFA_COLD_BAND
-#define BFA_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#else
+// (band / window changes laid out as cold branches were measured slower for the headline K1, 0.321 -> 0.341 ms)
 #define BFA_UNLIKELY(x) (x)
-#endif
 constexpr int WIN_MAX_FRAMES = 1536;
 // ... and every token costs the path at least one frame in a blank state; with a model that does not put noise between
 // phonemes that is about -15 per token after the boost, so past ~64 tokens the -1000 line is usually crossed too.
 // bfa_params.window_max_tokens > 0 overrides this limit (e.g. a large value for posteriors known to be CTC-like).
 constexpr int WIN_MAX_TOKENS = 64;
-// Window backpointers as lane masks written by the scalar unit (1) or as per-lane packed dwords (0, kept for A/B):
-// with masks the consumer spends one v_cmp per code bit (the result lands in an SGPR pair and leaves through
-// s_store_dwordx4) instead of v_cmp + v_addc, and K2 reads its frame's masks straight from memory (no LDS staging).
-#ifndef BFA_DBG_RELAX
-#define BFA_DBG_RELAX 0 // A/B builds of the packed-dword window variant: lets the (then unusable) wide classes compile
-#endif
-#ifndef BFA_WIN_SSTORE
-#define BFA_WIN_SSTORE 1
-#endif
-constexpr bool WIN_SSTORE = BFA_WIN_SSTORE != 0;
+// Window backpointers as lane masks written by the scalar unit: the consumer spends one v_cmp per code bit (the result
+// lands in an SGPR pair and leaves through s_store_dwordx4) instead of v_cmp + v_addc into per-lane packed dwords, and K2
+// reads its frame's masks straight from memory (no LDS staging).  (false: the packed-dword form, Rw <= 4 only.)
+constexpr bool WIN_SSTORE = true;
 __host__ __device__ inline int win_frames_per_word(int rw) { return rw == 1 ? 16 : (rw == 2 ? 8 : 4); }
 __host__ __device__ inline int win_class_for(int L, int bw, int Ts, int max_frames = WIN_MAX_FRAMES)
 {

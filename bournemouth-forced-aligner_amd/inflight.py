@@ -12,6 +12,7 @@ on the host).  Replaces nothing in the reference -- its batch loop is sequential
 import torch
 
 from .forced_alignment import AlignmentUtils
+from .utils import calculate_confidences_batch
 
 
 class BatchesInFlight:
@@ -33,22 +34,32 @@ class BatchesInFlight:
     def handle_slots(self):
         return [d.viterbi_decoder.handle_slot for d in self.decoders]
 
-    def submit(self, log_probs, true_seqs, pred_lens, true_seqs_lens, **kwargs):
+    def _one(self, k, log_probs, true_seqs, pred_lens, true_seqs_lens, confidences, kwargs):
+        res = self.decoders[k].decode_alignments_device(log_probs, true_seqs, pred_lens, true_seqs_lens, **kwargs)
+        if confidences:  # utils._calculate_confidences of the aligned tuples (core.py:936-937), right behind the alignment
+            res.conf, res.conf_status = calculate_confidences_batch(
+                log_probs, res.segs, res.seg_count, T_rows=pred_lens,
+                handle_slot=self.decoders[k].viterbi_decoder.handle_slot)
+        return res
+
+    def submit(self, log_probs, true_seqs, pred_lens, true_seqs_lens, confidences=False, **kwargs):
         """Enqueue one batch on the next slot (arguments of AlignmentUtils.decode_alignments_device).  The inputs must
         already be valid on the device when this is called from the caller's stream: the slot's stream first waits for
-        the caller's current stream.  Returns the AlignmentResult with `.stream` (None = the current stream) and `.wait()`."""
+        the caller's current stream.  `confidences`: also enqueue the confidence pass of the aligned tuples on the slot's
+        stream (`.conf` [B, seg_cap], `.conf_status` [B]).  Returns the AlignmentResult with `.stream` (None = the current
+        stream) and `.wait()`."""
         k = self._next
         self._next = (k + 1) % len(self.decoders)
         st = self.streams[k]
         if st is None:
-            res = self.decoders[k].decode_alignments_device(log_probs, true_seqs, pred_lens, true_seqs_lens, **kwargs)
+            res = self._one(k, log_probs, true_seqs, pred_lens, true_seqs_lens, confidences, kwargs)
             res.stream = None
             res.wait = lambda: None
             return res
         if self.wait_for_caller:
             st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
-            res = self.decoders[k].decode_alignments_device(log_probs, true_seqs, pred_lens, true_seqs_lens, **kwargs)
+            res = self._one(k, log_probs, true_seqs, pred_lens, true_seqs_lens, confidences, kwargs)
         res.stream = st
         res.wait = lambda s=st: torch.cuda.current_stream(self.device).wait_stream(s)
         return res

@@ -71,6 +71,27 @@ def test_min_phoneme_prob_against_reference(gpu_device):
         assert (mod.view(np.int32) == g[f"m{i}_mod"].view(np.int32)).all(), f"case {i}: prepared emissions differ"
 
 
+def test_narrow_widths_against_reference(gpu_device):
+    """Posterior widths below one host vector (C = 3..15): the reference boosts and re-normalises rows of any width
+    (forced_alignment.py:29-56), and torch sums fewer than sixteen exponentials one after the other.  log_softmax bit
+    patterns, tuples and framewise states against the reference's outputs (tests/golden/make_golden_narrow.py)."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, log_softmax
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "narrow_cases.npz"))
+    for C in (3, 4, 5, 8, 11, 12, 15):
+        got = log_softmax(torch.from_numpy(g[f"ls{C}_x"]).to(gpu_device)).cpu().numpy()
+        assert (got.view(np.int32) == g[f"ls{C}_y"].view(np.int32)).all(), C
+    meta = json.loads(str(g["meta"]))
+    for i, m in enumerate(meta):
+        lp = torch.from_numpy(g[f"n{i}_lp"]).to(gpu_device)
+        tk = torch.from_numpy(g[f"n{i}_tok"].astype(np.int64))
+        au = AlignmentUtils(m["blank"], 0, silence_anchors=0, ignore_noise=True, truly_forced=m["truly_forced"])
+        segs = au.decode_alignments(lp[None], tk[None], torch.tensor([m["T"]]), torch.tensor([m["S"]]))[0]
+        np.testing.assert_array_equal(np.array(segs, np.int32).reshape(-1, 4), g[f"n{i}_seg"], err_msg=f"case {i} {m}")
+        fp, fi, _ = au.viterbi_decoder.decode_with_forced_alignment(lp, tk)
+        np.testing.assert_array_equal(fp.cpu().numpy(), g[f"n{i}_fph"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(fi.cpu().numpy(), g[f"n{i}_fidx"], err_msg=f"case {i}")
+
+
 def test_log_softmax_against_torch_bits(gold, gpu_device):
     from bournemouth_forced_aligner_amd import log_softmax
     for C in (67, 17):

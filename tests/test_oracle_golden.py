@@ -226,3 +226,25 @@ def test_min_phoneme_prob_matches_reference(ora):
         _, mod_default = ora.prepare_emissions(lp, tk, ora.make_params(m["blank"], 0, 10, True, m["truly_forced"]))
         n_floor_matters += int(not np.array_equal(mod, mod_default))
     assert len(floors) == 6 and n_floor_matters >= 16  # the non-default floors do change the emissions
+
+
+def test_narrow_widths_match_reference(ora):
+    """Posterior widths below one host vector (C = 3..15; tests/golden/make_golden_narrow.py): torch sums the exponentials
+    of such a row one after the other -- log_softmax bit patterns, boosted / floored emissions, framewise states and
+    tuples are the reference's."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "narrow_cases.npz"))
+    for C in (3, 4, 5, 8, 11, 12, 15):
+        y = ora.log_softmax_rows(g[f"ls{C}_x"])
+        assert (y.view(np.int32) == g[f"ls{C}_y"].view(np.int32)).all(), C
+    meta = json.loads(str(g["meta"]))
+    assert len(meta) == 28
+    for i, m in enumerate(meta):
+        lp, tk = g[f"n{i}_lp"], g[f"n{i}_tok"]
+        prm = ora.make_params(m["blank"], 0, 0, True, m["truly_forced"])
+        res = ora.decode_alignments(lp[None], tk[None], [m["T"]], [m["S"]], prm)
+        got = np.array(ora.segments_as_lists(res)[0], np.int32).reshape(-1, 4)
+        np.testing.assert_array_equal(got, g[f"n{i}_seg"], err_msg=f"case {i} {m}")
+        np.testing.assert_array_equal(res["frame_ph"][0, :m["T"]], g[f"n{i}_fph"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(res["frame_idx"][0, :m["T"]], g[f"n{i}_fidx"], err_msg=f"case {i}")
+        rc, mod = ora.prepare_emissions(lp, tk, prm)
+        assert rc == 0 and (mod.view(np.int32) == g[f"n{i}_mod"].view(np.int32)).all(), f"case {i}"
