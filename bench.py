@@ -825,6 +825,8 @@ def realtext_main(args, rk):
         ap, ag = AlignmentUtils(blank_id=66, silence_id=0), AlignmentUtils(blank_id=16, silence_id=0)
         ap.viterbi_decoder.handle_slot = ag.viterbi_decoder.handle_slot = k
         slots.append((ap, ag))
+        # one call at a time: the heads of a call on two library streams; several in flight: head 1 on the side stream (bfa.h)
+        _lib.set_calls_in_flight(rk.local_rank, k, nfl > 1)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)] if nfl > 1 else [None]
     vd = slots[0][0].viterbi_decoder
     hints = [vd.class_mask_hint([T] * B, [S] * B, has_sil=True, n_classes=67),
@@ -1046,8 +1048,7 @@ def main():
                     help="headline: steps of the one-batch-in-flight leg that prices the kernel for `roofline`")
     ap.add_argument("--hw-queues", type=int, default=None,
                     help="GPU_MAX_HW_QUEUES for this process (the runtime maps HIP streams onto this many hardware queues, "
-                         "default 4; read once at HIP initialisation).  Default: 8 for --config realtext (two heads x "
-                         "several steps in flight are more chains than four queues), the runtime's own default otherwise")
+                         "default 4; read once at HIP initialisation).  Default: the runtime's own, for every config")
     ap.add_argument("--separate-post", action="store_true",
                     help="realtext A/B: bfa_postprocess / bfa_confidences as separate calls after bfa_align_heads")
     ap.add_argument("--row-pitch", type=int, default=0,
@@ -1090,8 +1091,6 @@ def main():
     args = ap.parse_args()
 
     # the hardware-queue count is a runtime setting read when HIP initialises (nothing has touched the device yet)
-    if args.hw_queues is None and args.config == "realtext":
-        args.hw_queues = 8
     if args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -14,13 +14,14 @@ BFA_ERR_WORKSPACE_TOO_SMALL, BFA_ERR_UNSUPPORTED = -4, -5
 ITEM_OK, ITEM_TOO_SHORT, ITEM_BAD_TOKEN, ITEM_TOO_LARGE, ITEM_SEG_OVERFLOW, ITEM_BAD_HINT = 0, 1, 2, 3, 4, 5
 HINT_NO_SILENCE_TARGETS = 1 << 16
 HINT_UNIFORM_LENGTHS = 1 << 17
+OPT_CALLS_IN_FLIGHT = 1  # bfa_set_option: the caller keeps several bfa_align_heads calls in flight (BatchesInFlight)
 MIX_MIN_BATCH = 64  # bfa_types.hpp: calls of at least this many utterances with non-uniform lengths take the one-kernel mixed path (k_mix)
 MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
            "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
            "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
-           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_profile_collect_spans"]
+           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_profile_collect_spans", "bfa_set_option"]
 
 
 class BfaParams(ctypes.Structure):
@@ -90,6 +91,7 @@ def lib():
     L.bfa_log_softmax.argtypes = [vp, vp, i64, vp, i64, i64, i32, vp]
     L.bfa_stitch_windows.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, i64, i64, vp]
     L.bfa_profile_enable.argtypes = [vp, i32]
+    L.bfa_set_option.argtypes = [vp, i32, i32]
     L.bfa_profile_collect_spans.argtypes = [vp, vp, vp, vp, i32]
     L.bfa_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32]
     _lib = L
@@ -112,6 +114,13 @@ def handle(device_index, slot=0):
                                f"(no GPU visible? this package has no CPU path)")
         _handles[key] = h
     return _handles[key]
+
+
+def set_calls_in_flight(device_index, slot, on):
+    """BFA_OPT_CALLS_IN_FLIGHT on the handle of (device, slot): the caller keeps several bfa_align_heads calls in flight
+    (one handle / stream each), see include/bfa.h."""
+    h = handle(device_index, slot)
+    check(lib().bfa_set_option(h, OPT_CALLS_IN_FLIGHT, 1 if on else 0), h, "bfa_set_option")
 
 
 def check(rc, h, what):

@@ -49,6 +49,12 @@ struct bfa_context {
     // bfa_align_heads: heads after the first are enqueued on this stream (forked from / joined into the caller's)
     hipStream_t head_stream = nullptr;
     hipEvent_t head_fork = nullptr, head_join = nullptr;
+    // ... or, when both exist, head k on pair[k % 2]: two streams of the caller's (normal) priority created one right after
+    // the other, so that the runtime's round-robin puts them on two DIFFERENT hardware queues whatever their number (four by
+    // default) -- the heads then share the machine from the start (see bfa_align_heads)
+    hipStream_t pair[2] = {nullptr, nullptr};
+    hipEvent_t pair_join[2] = {nullptr, nullptr};
+    int calls_in_flight = 0; // BFA_OPT_CALLS_IN_FLIGHT
 };
 
 namespace {
@@ -193,6 +199,16 @@ int bfa_create(bfa_handle *out, int device)
         int prev = 0;
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(device);
+        // (first: consecutive in the runtime's stream -> queue round-robin)
+#ifndef BFA_NO_PAIR_STREAMS // (A/B of the stream -> queue mapping with several calls in flight)
+        if (hipStreamCreateWithFlags(&h->pair[0], hipStreamNonBlocking) != hipSuccess) h->pair[0] = nullptr;
+#endif
+        if (h->pair[0] && hipStreamCreateWithFlags(&h->pair[1], hipStreamNonBlocking) != hipSuccess) h->pair[1] = nullptr;
+        for (int k = 0; k < 2; ++k)
+            if (h->pair[k] && hipEventCreateWithFlags(&h->pair_join[k], hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(h->pair[k]);
+                h->pair[k] = nullptr;
+            }
         bool ok = hipEventCreateWithFlags(&h->forked, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; ok && k < bfa_context::NAUX; ++k) {
             ok = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking) == hipSuccess &&
@@ -268,6 +284,10 @@ int bfa_destroy(bfa_handle h)
             if (h->aux_done[k]) (void)hipEventDestroy(h->aux_done[k]);
         }
         if (h->forked) (void)hipEventDestroy(h->forked);
+        for (int k = 0; k < 2; ++k) {
+            if (h->pair[k]) (void)hipStreamDestroy(h->pair[k]);
+            if (h->pair_join[k]) (void)hipEventDestroy(h->pair_join[k]);
+        }
         if (h->head_stream) (void)hipStreamDestroy(h->head_stream);
         if (h->head_fork) (void)hipEventDestroy(h->head_fork);
         if (h->head_join) (void)hipEventDestroy(h->head_join);
@@ -322,8 +342,13 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
     if (row_stats) {
         if (C < 16) return fail(h, BFA_ERR_UNSUPPORTED, "raw-logit input needs C >= 16 (vectorised softmax order)");
         // rows no kernel prepares (silence fills, frames beyond an utterance, items without a DP) keep this NaN and get
-        // their statistics from the first sparse reader that needs them (bfa_math.hpp: row_stats_on_demand)
-        if (hipMemsetAsync(row_stats, 0xFF, (size_t)B * (size_t)Tmax * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        // their statistics from the first sparse reader that needs them (bfa_math.hpp: row_stats_on_demand).  In the
+        // silence-anchored mode on the head widths K0 prepares EVERY row of EVERY utterance (a.row_stats2: k_silprob3) and
+        // marks the frames beyond an utterance itself: no 8 B x B x Tmax fill ahead of the call (32 MB per head for the
+        // 4096 x 1000 batch -- and, on the runtime's default four hardware queues, a fill kernel that sat 0.28 ms behind the
+        // other head's K0: profiles/r04_realtext_timeline_q4_before.txt)
+        if (!a.row_stats2 &&
+            hipMemsetAsync(row_stats, 0xFF, (size_t)B * (size_t)Tmax * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return fail(h, BFA_ERR_LAUNCH, "memset of row_stats failed");
     }
     a.B = B; a.Tmax = Tmax; a.C = C; a.Smax = Smax;
@@ -377,17 +402,30 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
     if (!heads || n_heads <= 0 || n_heads > 8) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad head list");
     for (int k = 0; k < n_heads; ++k)
         if (!heads[k].logits || !heads[k].out_row_stats) return fail(h, BFA_ERR_INVALID_ARGUMENT, "head without logits / out_row_stats");
-    const bool side = n_heads > 1 && h->head_stream != nullptr;
+    // Two heads side by side.  Round 3 put the later heads on ONE side stream of the lowest priority (a stream of another
+    // priority gets a hardware queue of its own) and head 0 on the caller's: with the runtime's default four queues the
+    // low-priority queue is not served while the other has workgroups waiting -- head 1's first kernel sat 0.27 ms behind
+    // head 0's K0 (profiles/r04_realtext_timeline_q4_before.txt) and a step took 2.1 ms against 1.7 with eight queues.
+    // Now head k runs on pair[k % 2], two streams of the caller's priority on two different queues; the caller's stream
+    // waits for both: 2.09 -> 1.75 ms one call at a time on four queues.  With several calls in flight (three handles) the
+    // six extra streams collide on the queues and the side stream is the better layout (1.46 against 1.66 ms per step):
+    // BFA_OPT_CALLS_IN_FLIGHT tells which caller this is.
+    const bool paired = n_heads > 1 && !h->calls_in_flight && h->pair[0] && h->pair[1] && h->head_fork;
+    const bool side = !paired && n_heads > 1 && h->head_stream != nullptr;
+    if (paired) {
+        (void)hipEventRecord(h->head_fork, (hipStream_t)stream);
+        (void)hipStreamWaitEvent(h->pair[0], h->head_fork, 0);
+        (void)hipStreamWaitEvent(h->pair[1], h->head_fork, 0);
+    }
     if (side) {
         (void)hipEventRecord(h->head_fork, (hipStream_t)stream);
         (void)hipStreamWaitEvent(h->head_stream, h->head_fork, 0);
     }
     int rc = BFA_OK;
-    // the later heads first, on the side stream; head 0 (the wide phoneme head) last on the caller's stream: its kernels
-    // are the long ones, the others fill in beside them
+    // the later heads first; head 0 (the wide phoneme head) last: its kernels are the long ones, the others fill in beside them
     for (int k = n_heads - 1; k >= 0 && rc == BFA_OK; --k) {
         const bfa_head &hd = heads[k];
-        void *st = (side && k > 0) ? (void *)h->head_stream : stream;
+        void *st = paired ? (void *)h->pair[k & 1] : ((side && k > 0) ? (void *)h->head_stream : stream);
         rc = align_impl(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, T_len, hd.tokens, S_len,
                         hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
                         hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st);
@@ -408,11 +446,24 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
             rc = bfa_confidences(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, nullptr, hd.out_segs,
                                  hd.seg_cap, hd.out_seg_count, hd.out_conf, hd.out_conf_status, st);
     }
+    if (paired) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipEventRecord(h->pair_join[k], h->pair[k]);
+            (void)hipStreamWaitEvent((hipStream_t)stream, h->pair_join[k], 0);
+        }
+    }
     if (side) {
         (void)hipEventRecord(h->head_join, h->head_stream);
         (void)hipStreamWaitEvent((hipStream_t)stream, h->head_join, 0);
     }
     return rc;
+}
+
+int bfa_set_option(bfa_handle h, int option, int value)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    if (option == BFA_OPT_CALLS_IN_FLIGHT) { h->calls_in_flight = value != 0; return BFA_OK; }
+    return fail(h, BFA_ERR_INVALID_ARGUMENT, "unknown option");
 }
 
 int bfa_prepare_emissions(bfa_handle h, const float *logp, int64_t strideB, int64_t strideT, int B, int Tmax, int C,

@@ -33,13 +33,13 @@ __device__ __forceinline__ RowLane make_rowlane(int nk, int j, int C, int blank,
 
 // narrowC = C for rows of fewer than sixteen columns (0 otherwise): the host then adds the C exponentials one after the other
 // (a partial vector is reduced element by element: ((e0 + e1) + e2) + ...), not in sixteen accumulators with a butterfly;
-// pinned by tests/golden/narrow_cases.npz (reference outputs for C = 3..15).  The lanes j >= C of a row hold copies of
-// column C - 1 (clamped loads), which the maximum does not mind and the sequential sum never reads.
+// pinned by tests/golden/narrow_cases.npz (reference outputs for C = 3..15).  The lanes j >= C of a row stay out of the
+// maximum (`valid`) and the sequential sum never reads them.
 template <int NK>
 __device__ __forceinline__ void softmax16(float (&x)[NK], uint32_t valid, float *mx_out = nullptr, float *ls_out = nullptr,
                                           int narrowC = 0)
 {
-    float mx = x[0];
+    float mx = (valid & 1u) ? x[0] : -__builtin_inff(); // (a lane without a column: only when C < 16)
 #pragma unroll
     for (int k = 1; k < NK; ++k)
         if (valid & (1u << k)) mx = __builtin_fmaxf(mx, x[k]);

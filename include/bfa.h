@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BFA_ABI_VERSION 3 /* v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
+#define BFA_ABI_VERSION 4 /* v4: bfa_set_option; v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
 
 typedef struct bfa_context *bfa_handle;
 
@@ -219,6 +219,17 @@ typedef struct {
 
 int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int Tmax, const int32_t *T_len,
                     const int32_t *S_len, void *stream);
+
+/*
+ * Handle options (none changes results).
+ *   BFA_OPT_CALLS_IN_FLIGHT  0 (default): the caller issues one bfa_align_heads call at a time, like the reference's loop
+ *       (core.py:897-937) -- the heads of a call run on two library streams of the caller's priority, i.e. on two
+ *       hardware queues even with the runtime's default of four, and share the machine from the first kernel on.
+ *       1: the caller keeps several calls in flight on several handles / streams (BatchesInFlight): head 0 stays on the
+ *       caller's stream, the others go to one low-priority side stream -- fewer streams per call, the calls overlap each other.
+ */
+#define BFA_OPT_CALLS_IN_FLIGHT 1
+int bfa_set_option(bfa_handle h, int option, int value);
 
 /*
  * Measurement hooks (bench.py): with on = n >= 1, every n-th bfa_align_batch call brackets its K1 launches
