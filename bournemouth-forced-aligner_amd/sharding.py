@@ -17,18 +17,18 @@ def utterance_cost(T, S):
     return T * (4 * S + 1)
 
 
-# What one rank's shard costs (MI355X, measured in round 3 on BASELINE config 4, profiles/r03_c4*.json): a call is bound
-# either by the serial chain of its longest utterance (the forward recurrence of forced_alignment.py:608-653 is serial in
-# t: ~0.42 us per frame beside the rest of the call, plus planning / walk) or by the machine (frames per second of the
-# whole call), whichever is longer.
-CHAIN_MS_PER_FRAME = 0.42e-3
-CHAIN_MS_FIXED = 0.10
+# What one rank's shard costs, for REPORTING only (bench.py prints it beside the measured time; the partition below does not
+# use it).  MI355X, round 4 (profiles/r04_c4*.json, r04_mix_workgroup_timeline.txt): the pairs of a full machine advance at one
+# shared pace per frame (~0.37 us: the SIMD's issue slots are shared out among its waves), so a call takes at least the
+# frames of its longest utterance at that pace plus its walk, or the machine rate over all its frames, whichever is longer.
+CHAIN_MS_PER_FRAME = 0.37e-3
+CHAIN_MS_FIXED = 0.20
 MACHINE_FRAMES_PER_MS = 7.0e6
 
 
 def predict_rank_ms(T_lens, S_lens):
     """{"chain_ms", "work_ms", "predicted_ms"} of one rank's shard: max(chain of the longest utterance, frames / machine
-    rate).  A model for reporting and for the partition below, not a guarantee."""
+    rate).  A model for reporting, not a guarantee; shard_utterances balances the DP work and nothing else."""
     T = np.asarray(T_lens, np.int64)
     if T.size == 0:
         return {"chain_ms": 0.0, "work_ms": 0.0, "predicted_ms": 0.0}
