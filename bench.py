@@ -416,7 +416,7 @@ def headline_main(args, rk):
     # HBM bytes of one K1 launch from the PMC passes of tools/profile.sh (committed under profiles/), if it was
     # taken on this workload; FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes
     traffic, tfile = None, None
-    for name in ("r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
+    for name in ("r04_k1_traffic.json", "r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and (B, T, S, C) == (4096, 1000, 40, 67) and not args.row_pitch:
             traffic, tfile = json.load(open(tpath))["traffic_bytes_per_launch"], name
@@ -1081,7 +1081,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="realtext A/B: the batch as this many bfa_align_heads calls per step")
     ap.add_argument("--halves", type=int, default=1,
                     help="c4: sub-shards of a rank's shard aligned side by side (own stream / decoder / library handle each)")
-    ap.add_argument("--chunk", type=int, default=16384, help="c4: utterances per bfa_align_batch call (one call per rank when the shard is smaller)")
+    ap.add_argument("--chunk", type=int, default=32768, help="c4: utterances per bfa_align_batch call (one call per rank when the shard is smaller; "
+                    "N = 1, same box: 7.14 ms as one call, 7.48 as two of 16384, 7.98 as four of 8192)")
     ap.add_argument("--seed", type=int, default=1004, help="c4: generator seed")
     ap.add_argument("--parity-sample", type=int, default=None,
                     help="utterances rank 0 checks against the oracle (c4: default 256, stratified; realtext: default 512)")

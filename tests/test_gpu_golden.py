@@ -392,6 +392,33 @@ def test_integration_option_b_snippet(gold, gpu_device):
     assert res["cases"] >= 3 and res["ok"] == res["cases"] and res["bad_token"] and not res["package_imported"], res
 
 
+def test_heads_layout_option_does_not_change_results(gold, gpu_device):
+    """bfa_set_option(BFA_OPT_CALLS_IN_FLIGHT): the two heads of a bfa_align_heads call on the pair of library streams
+    (default) or head 0 on the caller's stream and the rest on the side stream -- same tuples, confidences and statistics."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+    from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+    lc = torch.from_numpy(gold["l2_logits_class"]).to(gpu_device)
+    lg = torch.from_numpy(gold["l2_logits_group"]).to(gpu_device)
+    spec, slen = gold["l2_spectral_lens"].tolist(), gold["l2_seq_lens"].tolist()
+    tk, tg = torch.from_numpy(gold["l2_tokens"]), torch.from_numpy(gold["l2_group_tokens"])
+    aus = [AlignmentUtils(66, 0), AlignmentUtils(16, 0)]
+    for au in aus:
+        au.viterbi_decoder.handle_slot = 5
+    outs = []
+    for on in (False, True, False):
+        _lib.set_calls_in_flight(gpu_device.index or 0, 5, on)
+        res = align_heads(aus, [lc, lg], [tk, tg], spec, slen, post={"extend": True, "boundary_softness": 3, "confidences": True})
+        torch.cuda.synchronize()
+        outs.append([(r.segs.cpu().numpy().copy(), r.seg_count.cpu().numpy().copy(), r.conf.cpu().numpy().copy(), st.cpu().numpy().copy())
+                     for r, st in res])
+    for other in outs[1:]:
+        for (s0, c0, f0, t0), (s1, c1, f1, t1) in zip(outs[0], other):
+            keep = np.arange(s0.shape[1])[None, :] < c0[:, None]
+            assert np.array_equal(c0, c1) and np.array_equal(s0[keep], s1[keep])
+            assert np.array_equal(f0[keep].view(np.int32), f1[keep].view(np.int32))
+            assert np.array_equal(np.nan_to_num(t0).view(np.int32), np.nan_to_num(t1).view(np.int32))
+
+
 def test_fused_front_end_equals_two_pass(gpu_device):
     """raw logits -> bfa_align_heads (log_softmax inside K1's row preparation, row statistics for the
     sparse readers, both heads from one call) against the two-pass path (bfa_log_softmax, then one bfa_align_batch per

@@ -104,6 +104,10 @@ def test_bench_protocol_of_the_default_run(gpu_device):
     assert fl["busy_ms_per_launch"] <= out["ms_per_step"] * 1.02  # the kernel cannot be busy longer than the region
     # a lone kernel is not slower than a step of its own leg, and the leg's steps are plain stream-ordered calls
     assert r["kernel_ms"] < r["kernel_leg_ms_per_step"]
+    # a step is alignment + confidence pass by default; the alignment-only figure of earlier rounds rides along
+    ao = out["alignment_only"]
+    assert out["step"].startswith("K1 + K2 + K3") and 0 < ao["ms_per_step"] < out["ms_per_step"] and ao["value"] > out["value"]
+    assert r["confidence_pass_algorithmic_bytes"] > 64 * 4096 * 80 and 0.2 < r["whole_step_frac"] < 1.0
     print("3 in flight:", out["ms_per_step"], "ms/step; kernel alone", r["kernel_ms"], "frac", r["frac"], "whole step",
           r["whole_step_frac"], "busy/launch", fl["busy_ms_per_launch"])
 
@@ -155,6 +159,11 @@ def test_batches_in_flight_helper_matches_plain_calls(gpu_device):
         r.wait()  # the confidence pass below runs on the caller's stream
         cf, _ = calculate_confidences_batch(lp, r.segs, r.seg_count)
         got.append((n % len(work), r, cf))
+    # ... and with the confidence pass enqueued by the helper itself on the slot's stream (what a bench step is)
+    for n in range(5):
+        lp, tk, Tl, Sl = lens(work[n % len(work)])
+        r = bif.submit(lp, tk, Tl, Sl, confidences=True)
+        got.append((n % len(work), r, r.conf))
     bif.synchronize()
     torch.cuda.synchronize()
     for w, r, cf in got:

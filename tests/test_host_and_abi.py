@@ -541,3 +541,26 @@ def test_relaunch_under_torchrun_command_and_environment(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--config", "c4"]
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "GPU_MAX_HW_QUEUES" not in env
+
+
+def test_lazy_row_lists_behave_like_the_reference_list_of_lists():
+    """decode_alignments returns a LazyRowLists (forced_alignment.py:871,908 return list[list[tuple]]): indexing, negative
+    indices, slices, iteration, len, equality with plain lists (both ways), mutation of a row, tolist()."""
+    from bournemouth_forced_aligner_amd.forced_alignment import LazyRowLists, _ROW4, rows_as_tuple_lists
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 6, size=40)
+    rec = np.zeros(int(counts.sum()), _ROW4)
+    for k in ("phoneme", "start", "end", "target_idx"):
+        rec[k] = rng.integers(0, 1000, size=rec.shape[0])
+    plain = rows_as_tuple_lists(rec, counts)
+    lazy = LazyRowLists(rec, counts)
+    assert len(lazy) == 40 and lazy == plain and plain == lazy and not (lazy != plain)
+    assert lazy[7] == plain[7] and lazy[-1] == plain[-1] and lazy[3:9] == plain[3:9] and lazy[::-7] == plain[::-7]
+    assert [r for r in lazy] == plain and list(lazy) == plain and lazy.tolist() == plain
+    assert all(isinstance(t, tuple) and all(isinstance(v, int) for v in t) for r in lazy for t in r)
+    fresh = LazyRowLists(rec, counts)
+    fresh[5].append((1, 2, 3, 4))          # a row is a real list: kept once it has been built
+    assert fresh[5][-1] == (1, 2, 3, 4) and fresh.tolist()[5][-1] == (1, 2, 3, 4) and fresh != plain
+    with pytest.raises(IndexError):
+        lazy[40]
+    assert LazyRowLists(rec[:0], []) == [] and len(LazyRowLists(rec[:0], [0, 0])) == 2
