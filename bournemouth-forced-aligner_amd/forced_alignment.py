@@ -115,6 +115,51 @@ class LazyRowLists(collections.abc.Sequence):
         return repr(self.tolist())
 
 
+class LazyRowDicts(collections.abc.Sequence):
+    """list[B]-like of per-utterance dicts {head: rows} (core.py:958-964: `phoneme_timestamps`, `group_timestamps`) over
+    LazyRowLists: the dict of utterance b, with that utterance's tuples, is built when it is asked for and kept."""
+    __slots__ = ("_heads", "_n", "_dicts")
+
+    def __init__(self, heads, n):
+        self._heads = heads  # {key: LazyRowLists}
+        self._n = n
+        self._dicts = [None] * n
+
+    def __len__(self):
+        return self._n
+
+    def _one(self, b):
+        d = self._dicts[b]
+        if d is None:
+            d = self._dicts[b] = {k: v[b] for k, v in self._heads.items()}
+        return d
+
+    def __getitem__(self, b):
+        if isinstance(b, slice):
+            return [self._one(i) for i in range(*b.indices(self._n))]
+        if b < -self._n or b >= self._n:
+            raise IndexError("list index out of range")
+        return self._one(b % self._n if self._n else 0)
+
+    def tolist(self):
+        for v in self._heads.values():
+            v.tolist()  # every row of a head in one numpy pass
+        return [self._one(b) for b in range(self._n)]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, LazyRowDicts)):
+            return len(other) == self._n and all(a == b for a, b in zip(self.tolist(), other))
+        return NotImplemented
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(self.tolist())
+
+
 def rows_as_tuple_lists(records, counts):
     """`records`: a flat numpy STRUCTURED array, one record per valid row of the batch in utterance order; `counts` [B].
     Returns list[B] of list[tuple]: numpy turns a record into a tuple of python scalars in C, the flat list is then cut

@@ -7,6 +7,12 @@ last() { grep "^{" | tail -1; }
 timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $OUT/smoke.log
 python bench.py --steps 20 --warmup 5 2>$OUT/bench.err | last > $OUT/bench.json
+# (a box of the pool has been seen running every large kernel at a third of its occupancy -- headline K1 0.69 ms with the same
+# instruction counts: numbers from such a box are not recorded)
+python - <<PY || { echo "this box is degraded (headline K1 above 0.45 ms): not measuring on it"; exit 3; }
+import json,sys
+k=json.load(open("$OUT/bench.json"))["roofline"]["kernel_ms"]; print("sanity: headline K1 %.4f ms" % k); sys.exit(0 if k < 0.45 else 1)
+PY
 python bench.py --steps 20 --warmup 5 --inflight 1 --no-cpu 2>/dev/null | last > $OUT/bench_inflight1.json
 python bench.py --steps 20 --warmup 5 --no-cpu --no-confidences 2>/dev/null | last > $OUT/bench_alignment_only.json
 rm -f $OUT/bench_runs.jsonl; for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | last >> $OUT/bench_runs.jsonl; done
