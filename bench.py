@@ -7,9 +7,11 @@ log-probabilities.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
       headline: BASELINE.json configs[2] ("batch=4096 T=1000 |tokens|=40 ph66") PER GPU, weak scaling.  The K timed
-      steps are issued with three batches in flight (step i on stream i % 3 with its own decoder / library handle /
+      steps are issued with four batches in flight (step i on stream i % 4 with its own decoder / library handle /
       workspace / outputs; --inflight 1 = one batch at a time): the latency-bound tail of a step runs beside the forward
-      kernel of the next ones.  Every step does all of its work inside the timed region; value = frames / wall time.
+      kernel of the next ones.  A step is alignment (K1), walk / tuples (K2) AND the confidence pass of the aligned tuples
+      (K3, core.py:936-937) unless --no-confidences; `alignment_only` in the line is the K1 + K2 step of rounds 1-3.
+      Every step does all of its work inside the timed region; value = frames / wall time.
   python bench.py --config c4 [--gpus N]
       BASELINE.json configs[3]: global B = 32768, T in [200,3000], S = T // 25 (seed 1004), LPT-sharded over the N
       ranks (sharding.shard_utterances), every rank synthesises and aligns only its shard, the result records are
@@ -206,12 +208,13 @@ def headline_main(args, rk):
     B, T, S, C = args.batch, args.frames, args.tokens, args.classes
     blank, sil = C - 1, 0
     K = args.steps
-    # Batches in flight (default 3): step i runs on stream i % 3 with decoder i % 3 (own library handle, workspace and
+    # Batches in flight (default 4; 3 until round 4, when the confidence pass joined the step: 0.407 against 0.423 ms on one box,
+    # tools/experiments/scripts/r4_inflight.sh): step i runs on stream i % n with decoder i % n (own library handle, workspace and
     # outputs), so the tail of a step (rerun launch, walk, run-length encoding: ~65 us of latency chains that leave the
     # machine mostly idle) and the ramp-down of its K1 overlap the K1 of the next steps.  `value` = frames / wall time.
     # The K1 launches of different steps then overlap each other, so a launch's duration there says how long it SHARED
     # the machine: the roofline entry is priced by a separate leg of this same run with ONE batch in flight (below).
-    inflight = max(1, args.inflight if args.inflight is not None else 3)
+    inflight = max(1, args.inflight if args.inflight is not None else 4)
     nbuf = max(2, inflight)
     # distinct batches so consecutive steps never stream the same 1.1 GB (> the 256 MB Infinity Cache anyway)
     bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
@@ -1064,7 +1067,7 @@ def main():
                          "the first window)")
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight, each on its own stream with its own decoder / library handle / workspace "
-                         "(default: 3 for the headline, 1 for --config c4)")
+                         "(default: 4 for the headline, 3 for --config realtext, 1 for --config c4)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="utterances timed on the host oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-confidences", action="store_true",

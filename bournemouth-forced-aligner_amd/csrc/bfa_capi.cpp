@@ -508,6 +508,7 @@ int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t s
     DeviceGuard guard(h);
     if (!logp || !segs || !seg_count || !out_conf) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
+#ifndef BFA_CONF_TUPLE_PER_LANE // (A/B: the confidences alone through the tuple-per-lane kernel)
     if (staged_post()) { // the probabilities staged in LDS (k_postconf); falls through when the shapes do not fit
         const int lrc = bfa_launch_postconf(logp, row_stats, strideB, strideT, B, Tmax, C, nullptr, const_cast<bfa_segment *>(segs),
                                             seg_cap, const_cast<int32_t *>(seg_count), 0, 0, 0.0, 0.0, 1, T_rows, out_conf,
@@ -515,6 +516,7 @@ int bfa_confidences(bfa_handle h, const float *logp, float *row_stats, int64_t s
         if (lrc == 0) return BFA_OK;
         if (lrc > 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)lrc));
     }
+#endif
     bfa::ConfArgs a;
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.T_rows = T_rows;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.conf = out_conf; a.status = out_item_status;

@@ -87,12 +87,12 @@ def test_headline_mode_multi_rank_path_on_nccl(gpu_device):
 
 def test_bench_protocol_of_the_default_run(gpu_device):
     """`python bench.py --steps 20 --warmup 5` (what the driver runs): five windows of exactly 20 steps (>= 100 timed
-    steps) with three batches in flight; the warm-up that really ran is reported; `roofline` is priced by
+    steps) with four batches in flight; the warm-up that really ran is reported; `roofline` is priced by
     the one-batch-in-flight leg of the same run (no launch overlaps another there), while the brackets of the reported
     windows -- which do overlap -- are kept under `in_flight`."""
     out = _bench_json(["--steps", "20", "--warmup", "5", "--no-cpu", "--settle-ms", "60"])
     r, t = out["roofline"], out["timing"]
-    assert out["config"]["batches_in_flight"] == 3 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["config"]["batches_in_flight"] == 4 and out["steps"] == 20 and out["warmup"] == 5
     assert t["windows"] == 5 and t["timed_steps_total"] == 100 and len(t["window_ms_per_step"]["all"]) == 5
     assert t["warmup_effective_steps"] >= 5 + 20 and t["warmup_requested_steps"] == 5
     assert abs(out["ms_per_step"] - np.mean(t["window_ms_per_step"]["all"])) < 1e-6 * out["ms_per_step"] + 1e-9
@@ -108,7 +108,7 @@ def test_bench_protocol_of_the_default_run(gpu_device):
     ao = out["alignment_only"]
     assert out["step"].startswith("K1 + K2 + K3") and 0 < ao["ms_per_step"] < out["ms_per_step"] and ao["value"] > out["value"]
     assert r["confidence_pass_algorithmic_bytes"] > 64 * 4096 * 80 and 0.2 < r["whole_step_frac"] < 1.0
-    print("3 in flight:", out["ms_per_step"], "ms/step; kernel alone", r["kernel_ms"], "frac", r["frac"], "whole step",
+    print("4 in flight:", out["ms_per_step"], "ms/step; kernel alone", r["kernel_ms"], "frac", r["frac"], "whole step",
           r["whole_step_frac"], "busy/launch", fl["busy_ms_per_launch"])
 
 
