@@ -775,7 +775,7 @@ def c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed):
     order = np.argsort(T, kind="stable")
     longest = order[-min(32, n):]
     strat = order[np.linspace(0, n_total - 1, max(0, n - len(longest))).astype(np.int64)]
-    sample = np.unique(np.concatenate([longest, strat]))
+    sample = np.unique(np.concatenate([longest, strat])) if n < n_total else np.arange(n_total)  # (--parity-sample >= batch: everything)
     prm = ora.make_params(C - 1, 0)
     mism, bad_inputs, frames = 0, 0, 0
     w = 0.0

@@ -40,6 +40,8 @@ def run(nb=200, seed=1, dev=None):
         min_prob = float(rng.choice([1e-8, 1e-8, 1e-8, 1e-4, 0.05]))  # ViterbiDecoder.min_phoneme_prob (forced_alignment.py:20)
         regime = int(rng.integers(0, 5))
         n = int(rng.integers(4, 40))
+        if rng.integers(0, 3) == 0:  # 64 utterances or more with different lengths: the one-kernel mixed-length path (k_mix)
+            n = int(rng.integers(64, 150))
         lps, toks = [], []
         for _ in range(n):
             if regime == 0:      # headline-like: window classes

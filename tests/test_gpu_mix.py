@@ -87,3 +87,27 @@ def test_mixed_call_order_is_a_permutation(gpu_device):
     torch.cuda.synchronize()
     assert int((res.status != 0).sum()) == 0
     assert np.array_equal(res.seg_count.cpu().numpy(), Sl)
+
+
+def test_mixed_call_of_long_paths_only(ora, gpu_device):
+    """a mixed call whose utterances all have 60-420 tokens (the soak's "long" regime): window classes Rw 3..8 (exact, as
+    there are more than 64 tokens), full layouts up to R = 16 -- k_mix takes the narrow ones, the class kernels the rest"""
+    rng = np.random.default_rng(9400)
+    C, blank = 67, 66
+    lps, toks = [], []
+    for _ in range(96):
+        S = int(rng.integers(60, 420)); T = int(rng.integers(4 * S + 1, 4 * S + 900))
+        if rng.integers(0, 4) == 0:
+            T = int(rng.integers(3 * S + 1, 4 * S + 1))  # stride 3
+        lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=blank, peak=float(rng.choice([9.0, 3.0, 0.2])), sigma=1.0, repeat_rate=0.1)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, blank)
+    for tf in (True, False):
+        for hint in (0, None):
+            for max_tokens in (None, 4096):  # 4096: the wide classes Rw = 6 / 8 stay FAST windows beside k_mix's exact narrow ones
+                res, exp = _run(ora, gpu_device, lp, tk, T_len, S_len, C, tf, max_tokens=max_tokens, class_mask=hint)
+                st = res.status.cpu().numpy()
+                bad = np.nonzero(st != exp["status"])[0]
+                assert bad.size == 0, [(int(T_len[b]), int(S_len[b]), int(st[b])) for b in bad[:12]]
+                _compare(res, exp, T_len)

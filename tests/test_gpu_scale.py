@@ -29,14 +29,17 @@ def test_c4_mode_world_size_1_nccl(gpu_device):
     """BASELINE.json configs[3] end to end at reduced global batch: plan -> LPT shard -> per-rank synthesis and
     alignment in length-sorted calls -> sharding.gather_results over an RCCL process group -> rank 0 re-synthesises a
     stratified sample (incl. the longest utterances) and compares the GATHERED records with the oracle."""
-    out = _bench_json(["--config", "c4", "--global-batch", "1536", "--chunk", "512", "--steps", "2", "--warmup", "1",
-                       "--parity-sample", "512"])
-    assert out["n_gpus"] == 1 and len(out["ranks"]) == 1 and "cuda:0" == out["ranks"][0]["device"]
-    ps = out["parity_sample"]
-    assert ps["utterances"] >= 480 and ps["mismatching_utterances"] == 0 and ps["regenerated_inputs_differing"] == 0
-    assert ps["longest_T"] >= 2990  # the sample holds the longest utterances of the batch
-    assert out["shard_sizes"] == [1536] and out["gather_ms"] is not None and out["value"] > 0
-    assert out["scaling"] == "strong" and out["frames_per_step"] > 1536 * 200
+    # EVERY utterance of the reduced batch is compared, once as length-sorted calls of 512 (narrow length ranges: the per-class
+    # kernels) and once as ONE call (the mixed-length path, k_mix)
+    for chunk in ("512", "32768"):
+        out = _bench_json(["--config", "c4", "--global-batch", "1536", "--chunk", chunk, "--steps", "2", "--warmup", "1",
+                           "--parity-sample", "1536"])
+        assert out["n_gpus"] == 1 and len(out["ranks"]) == 1 and "cuda:0" == out["ranks"][0]["device"]
+        ps = out["parity_sample"]
+        assert ps["utterances"] == 1536 and ps["mismatching_utterances"] == 0 and ps["regenerated_inputs_differing"] == 0
+        assert ps["longest_T"] >= 2990  # the sample holds the longest utterances of the batch
+        assert out["shard_sizes"] == [1536] and out["gather_ms"] is not None and out["value"] > 0
+        assert out["scaling"] == "strong" and out["frames_per_step"] > 1536 * 200
 
 
 def _batch_vs_oracle(ora, dev, B, T, S, seed, n_check):
@@ -69,10 +72,10 @@ def test_config_c2_full_batch_against_oracle(ora, gpu_device):
     _batch_vs_oracle(ora, gpu_device, 256, 600, 20, 1002, 256)
 
 
-def test_config_c3_slice_against_oracle(ora, gpu_device):
-    """BASELINE.json configs[2] (the headline batch=4096, T=1000, |tokens|=40) aligned at full batch size, a
-    512-utterance slice of it compared with the oracle (framewise states, tuples, confidence bit patterns)."""
-    _batch_vs_oracle(ora, gpu_device, 4096, 1000, 40, 1003, 512)
+def test_config_c3_full_batch_against_oracle(ora, gpu_device):
+    """BASELINE.json configs[2] (the headline batch=4096, T=1000, |tokens|=40) aligned at full batch size, EVERY utterance
+    of it compared with the oracle (framewise states, tuples, confidence bit patterns)."""
+    _batch_vs_oracle(ora, gpu_device, 4096, 1000, 40, 1003, 4096)
 
 
 def test_headline_mode_multi_rank_path_on_nccl(gpu_device):
