@@ -3,7 +3,8 @@
 oracle (run on the GPU box).  Every batch draws its own head width, flags, floor probability, length ranges and posterior
 sharpness; integer outputs must be identical.  `run()` is what `pytest -m gpu` calls on a fixed-seed slice
 (tests/test_gpu_parity.py::test_soak_slice); the full soak takes minutes, prints one line per mismatch and a summary, and
-with --record appends its per-seed counts to a JSON file (profiles/r03_soak.json)."""
+with --record appends its per-seed counts to a JSON file (profiles/r04_soak.json).  A third of the batches hold 64-150
+utterances: mixed-length calls through the one-kernel path (k_mix)."""
 import os
 import sys
 import time
