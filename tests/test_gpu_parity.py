@@ -650,6 +650,36 @@ def test_one_kernel_small_batch_path(ora, gpu_device):
             assert torch.equal(plain.frame_phonemes[ok], res.frame_phonemes[ok]) and torch.equal(plain.frame_phonemes_idx[ok], res.frame_phonemes_idx[ok])
 
 
+def test_one_kernel_tile_and_group_edges(ora, gpu_device):
+    """k_one's consumer takes the tiles in groups of two between barriers and looks at the give-up flag every fourth group:
+    utterance lengths around every tile (16 frames) and group (32 frames) boundary and around the flag's period (128 frames),
+    one length per call so that the call is ONE window class, each of the three classes (Rw = 1, 2, 3), sharp posteriors
+    (the window's result stands) and flat ones (the consumer gives up on the way or ends at the sentinel: full-layout
+    rerun in the same kernel), both final-state rules.  At least 90 of the 150 calls must be calls the library takes the one-kernel path on."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+    C = 67
+    taken = 0
+    lens = [81, 95, 96, 97, 111, 112, 113, 127, 128, 129, 143, 144, 145, 159, 160, 161, 191, 192, 193, 255, 256, 257, 271, 272, 273, 383, 384, 385, 400, 511, 512, 513, 640, 641]
+    for i, T in enumerate(lens):
+        for S in (18, 22, 40, 57, 60, (T - 1) // 3 - 1):   # Rw = 1, 1, 2, 2, 3 (stride 4); a stride-3 path
+            if 3 * S + 1 > T or S > 64:
+                continue
+            peak, tf = ((9.0, True), (0.3, True), (0.4, False), (7.0, False))[(i + S) % 4]
+            rng = np.random.default_rng(7000 + 13 * T + S)
+            lps, toks = [], []
+            for k in range(5):
+                lp, tk, _ = cases.planted_case(rng, T, S, C=C, blank=C - 1, peak=peak, sigma=1.0, repeat_rate=0.1)
+                lps.append(lp); toks.append(tk)
+            lp, tk, T_len, S_len = cases.pad_batch(lps, toks, C, C - 1)
+            au = AlignmentUtils(C - 1, 0, silence_anchors=10, truly_forced=tf)
+            hint = au.viterbi_decoder.class_mask_hint(T_len, S_len, False, n_classes=C)
+            if hint is not None and (hint & ~(_lib.HINT_NO_SILENCE_TARGETS | _lib.HINT_UNIFORM_LENGTHS)) in (1 << 8, 1 << 9, 1 << 10):
+                taken += 1
+            res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, C, anchors=10, tf=tf)
+            _compare(res, exp, T_len)
+    assert taken >= 90, taken
+
+
 def test_uniform_lengths_hint_only_moves_the_work(ora, gpu_device):
     """BFA_HINT_UNIFORM_LENGTHS lets each XCD take one contiguous eighth of the batch (workgroup id -> utterance slot through
     xcd_eighth): the same arrays as without the hint, for batch sizes that are and are not multiples of 8, in the window,
