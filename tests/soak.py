@@ -39,9 +39,10 @@ def run(nb=200, seed=1, dev=None):
         boost = bool(rng.integers(0, 6) != 0)
         enf = bool(rng.integers(0, 6) != 0)
         min_prob = float(rng.choice([1e-8, 1e-8, 1e-8, 1e-4, 0.05]))  # ViterbiDecoder.min_phoneme_prob (forced_alignment.py:20)
-        regime = int(rng.integers(0, 5))
+        regime = int(rng.integers(0, 6))
+        one_lo, one_hi = [(15, 23), (33, 58), (58, 65)][int(rng.integers(0, 3))]  # regime 5: token counts of ONE window class (Rw = 1 / 2 / 3)
         n = int(rng.integers(4, 40))
-        if rng.integers(0, 3) == 0:  # 64 utterances or more with different lengths: the one-kernel mixed-length path (k_mix)
+        if rng.integers(0, 3) == 0 and regime != 5:  # 64 utterances or more with different lengths: the one-kernel mixed-length path (k_mix)
             n = int(rng.integers(64, 150))
         lps, toks = [], []
         for _ in range(n):
@@ -53,6 +54,8 @@ def run(nb=200, seed=1, dev=None):
                 S = int(rng.integers(60, 420)); T = int(rng.integers(4 * S + 1, 4 * S + 900))
             elif regime == 3:    # tiny
                 S = int(rng.integers(0, 12)); T = int(rng.integers(1, 90))
+            elif regime == 5:    # a small call of one sliding-window class: plan + DP + rerun + walk in one kernel (k_one)
+                S = int(rng.integers(one_lo, one_hi)); T = int(rng.integers(4 * S + 1, 4 * S + 700))
             else:                # mixed
                 T = int(rng.integers(8, 1200)); S = int(rng.integers(1, max(2, T // 3)))
             peak = float(rng.choice([9.0, 6.0, 3.0, 1.0, 0.2]))
