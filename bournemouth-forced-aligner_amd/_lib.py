@@ -15,7 +15,8 @@ ITEM_OK, ITEM_TOO_SHORT, ITEM_BAD_TOKEN, ITEM_TOO_LARGE, ITEM_SEG_OVERFLOW, ITEM
 HINT_NO_SILENCE_TARGETS = 1 << 16
 HINT_UNIFORM_LENGTHS = 1 << 17
 OPT_CALLS_IN_FLIGHT = 1  # bfa_set_option: the caller keeps several bfa_align_heads calls in flight (BatchesInFlight)
-MIX_MIN_BATCH = 64  # bfa_types.hpp: calls of at least this many utterances with non-uniform lengths take the one-kernel mixed path (k_mix)
+MIX_MIN_BATCH = 2   # bfa_types.hpp: calls of at least this many utterances with non-uniform lengths take the one-kernel mixed path (k_mix)
+ONE_MAX_BATCH = 1024  # bfa_types.hpp: calls of at most this many utterances in ONE fast-window class take the one-kernel path of small calls (k_one)
 MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",

@@ -285,7 +285,13 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // Mixed-length calls (the caller has not promised uniform lengths): ONE kernel aligns and walks every utterance of the
     // narrow classes (bfa_dp4.inc: k_mix) -- the exact window for every stride >= 3 window item of the classes Rw <= 4 (a hinted
     // fast-window class stands for its exact twin), the full layout R <= 4 -- in longest-first order (k_order).
-    const bool use_mix = mode == 0 && !seg_possible && (a.C == 67 || a.C == 17) && wall != 0 && a.B >= MIX_MIN_BATCH &&
+    // (a small call the hint puts in ONE fast-window class is k_one's, see below)
+    const unsigned hw1 = (p.class_mask >> 8) & 0xffu;
+    const int rw1 = (hw1 == 1u) ? 1 : (hw1 == 2u) ? 2 : (hw1 == 4u) ? 3 : 0;
+    const bool one_ok = !seg_possible && mode == 0 && (a.C == 67 || a.C == 17) && rw1 > 0 && (p.class_mask & 0x7fu) == 0 &&
+                        ((p.class_mask >> 20) & 0xffu) == 0 && ((wmask >> (rw1 > 0 ? rw1 - 1 : 0)) & 1u) && a.B <= ONE_MAX_BATCH && Lmax <= 256 &&
+                        a.frame_ph && a.frame_idx;
+    const bool use_mix = mode == 0 && !seg_possible && (a.C == 67 || a.C == 17) && wall != 0 && a.B >= MIX_MIN_BATCH && !one_ok &&
                          !(p.class_mask & BFA_HINT_UNIFORM_LENGTHS) && a.frame_ph && a.frame_idx;
     if (use_mix) {
         const unsigned narrow_x = hinted ? (wall & (((unsigned)p.class_mask >> 20) | ((unsigned)p.class_mask >> 8)) & 0xfu) : (wall & 0xfu);
@@ -305,18 +311,12 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     a.xcd_contig = (mode == 0 && (p.class_mask & BFA_HINT_UNIFORM_LENGTHS)) ? 1 : 0;
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
-    {
-        constexpr int one_max = ONE_MAX_BATCH;
-        const unsigned hw = (p.class_mask >> 8) & 0xffu;
-        const int rw1 = (hw == 1u) ? 1 : (hw == 2u) ? 2 : (hw == 4u) ? 3 : 0;
-        if (fused_k2 && rw1 > 0 && (p.class_mask & 0x7fu) == 0 && (xmask & 0xafu) == 0 && (wmask >> (rw1 - 1) & 1u) && a.B <= one_max && Lmax <= 256 &&
-            a.frame_ph && a.frame_idx) {
-            a.p.xwin_mask = 0; // (k_one reruns its own window failures with the full layout)
-            if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
-            if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);
-            if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
-            return (int)hipGetLastError();
-        }
+    if (one_ok && (xmask & 0xafu) == 0) {
+        a.p.xwin_mask = 0; // (k_one reruns its own window failures with the full layout)
+        if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+        if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);
+        if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
+        return (int)hipGetLastError();
     }
     if (seg_possible) (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
     else a.p.win_mask |= 0x80000000u; // k_plan zeroes the counters (see there)

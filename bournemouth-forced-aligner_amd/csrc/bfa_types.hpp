@@ -53,9 +53,10 @@ constexpr int XW_FAST = 0, XW_EXACT = 1, XW_REDO = 2, XW_REDONE = 3;
 constexpr uint32_t XWIN_REDO = 0x100u, XWIN_MIX = 0x200u;
 constexpr int ONE_MAX_BATCH = 1024; // largest single-class call that takes the one-kernel path (k_one; 8192: 0.62 ms against 0.32 + 0.06 for the headline batch)
 #ifndef BFA_MIX_MIN_BATCH
-#define BFA_MIX_MIN_BATCH 64
+#define BFA_MIX_MIN_BATCH 2
 #endif
-constexpr int MIX_MIN_BATCH = BFA_MIX_MIN_BATCH; // smaller calls keep the per-class kernels (a lone long utterance: its dead tail runs segment-parallel there)
+constexpr int MIX_MIN_BATCH = BFA_MIX_MIN_BATCH; // a lone utterance keeps the per-class kernels (its dead tail runs segment-parallel there); 64 until the
+                                                 // end of round 4: calls of 4-48 sentences took 1.3-1.7 x as long through the class kernels (profiles/r04_latency_mixed.txt)
 
 // one wavefront's candidates for the final-state rule (forced_alignment.py:656-682) when a DP is spread over
 // several wavefronts (k_dp_big, k_dp5): rightmost / best state above the sentinel, best of all, dp[L-1], dp[L-2]

@@ -357,9 +357,13 @@ class ViterbiDecoder:
             # of the same class, bits 20-27 (strides >= 3, standard mode only: bfa_plan.inc)
             exact = (rw > 0) & ((T > max_frm) | (S > max_tok))
             no_seg = not (has_sil and anchor_pauses and self.silence_anchors > 0)
-            # a mixed-length call (bfa_launch_align: no promise of uniform lengths, 64 utterances or more): every stride >= 3
+            # a mixed-length call (bfa_launch_align: no promise of uniform lengths, two utterances or more): every stride >= 3
             # window item of the classes Rw <= 4 is an exact-window item (k_mix aligns and walks it in one workgroup)
-            if no_seg and T.size >= _lib.MIX_MIN_BATCH and not self._uniform(T):
+            # (not a small call whose DPs all sit in ONE fast-window class of at most 256 states: that one is k_one's)
+            dp_rw = rw[is_dp]
+            one_class = (T.size < 64 and dp_rw.size > 0 and int(dp_rw.min()) == int(dp_rw.max()) and 1 <= int(dp_rw.max()) <= 3
+                         and not bool(exact.any()) and int(L[is_dp].max()) <= 256)
+            if no_seg and T.size >= _lib.MIX_MIN_BATCH and not self._uniform(T) and not one_class:
                 exact = exact | ((rw > 0) & (rw <= 4) & (stride >= 3))
             rx = np.where(exact & (stride >= 3) & no_seg, rw, 0)
             rw[exact] = 0

@@ -115,7 +115,8 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 25     # L=721, bw=180 -> exact Rw=6
     assert vd.class_mask_hint([400], [180], has_sil=False, n_classes=67) == NS | 1 << 3      # stride 2 (L=361): no exact window, full layout R=6
     vd.window_max_tokens = 4096
-    assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 11) | 0b1  # L=481 -> Rw=4
+    assert vd.class_mask_hint([1500], [120], has_sil=False, n_classes=67) == NS | (1 << 11)  # L=481 -> Rw=4
+    assert vd.class_mask_hint([1500, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 23) | 0b1  # two lengths in one call: the mixed path, exact Rw=4
     assert vd.class_mask_hint([3000, 200], [120, 8], has_sil=False, n_classes=67) == NS | (1 << 23) | 0b1  # T > 1536: exact Rw=4
     assert vd.class_mask_hint([900], [180], has_sil=False, n_classes=67) == NS | 1 << 13     # L=721, bw=180 -> 372 states -> Rw=6
     # bit 17 (speed hint): 64 or more utterances with about the same number of frames
@@ -123,9 +124,12 @@ def test_class_mask_hint():
     assert vd.class_mask_hint([1000] * 64, [40] * 64, has_sil=False, n_classes=67) == NS | UL | 1 << 9
     assert vd.class_mask_hint([1000] * 63 + [900], [40] * 64, has_sil=False, n_classes=67) == NS | UL | 1 << 9
     # 64 or more utterances whose lengths differ: the mixed-length path (k_mix) -- the stride >= 3 window items of the classes
-    # Rw <= 4 are exact-window items (bits 20-23); stride-2 paths keep the fast window; fewer than 64: as before
+    # Rw <= 4 are exact-window items (bits 20-23); stride-2 paths keep the fast window.  Since the end of round 4 this holds
+    # from TWO utterances on -- except a call of fewer than 64 utterances whose DPs all sit in ONE fast-window class (k_one's)
     assert vd.class_mask_hint([1000] * 63 + [500], [40] * 63 + [20], has_sil=False, n_classes=67) == NS | 1 << 21 | 1 << 20
-    assert vd.class_mask_hint([1000] * 62 + [500], [40] * 62 + [20], has_sil=False, n_classes=67) == NS | 1 << 9 | 1 << 8
+    assert vd.class_mask_hint([1000] * 62 + [500], [40] * 62 + [20], has_sil=False, n_classes=67) == NS | 1 << 21 | 1 << 20
+    assert vd.class_mask_hint([1000, 500], [40, 20], has_sil=False, n_classes=67) == NS | 1 << 21 | 1 << 20
+    assert vd.class_mask_hint([1000, 700, 900], [40, 35, 42], has_sil=False, n_classes=67) == NS | 1 << 9   # one class (Rw=2): k_one
     assert vd.class_mask_hint([1000] * 63 + [300], [40] * 63 + [100], has_sil=False, n_classes=67) == NS | 1 << 21 | 1 << 9  # stride 2, L=201: fast Rw=2
     assert vd.class_mask_hint([1000] * 63 + [500], [40] * 63 + [20], has_sil=True, n_classes=67) == 0b11 | 1 << 9 | 1 << 8  # SIL possible: no mixed path (the library drops the window bits in that mode)
     assert vd.class_mask_hint([900], [187], has_sil=False, n_classes=67) == NS | 1 << 15     # L=749, bw=187 -> 390 states -> Rw=8

@@ -12,7 +12,7 @@ if os.environ.get("BFA_MIXMIN"):
 dev = torch.device("cuda", 0)
 au = AlignmentUtils(66, 0, silence_anchors=10)
 for tmax in (1500, 3000):
-    for B in (4, 8, 16, 32, 48, 64, 96):
+    for B in (2, 3, 4, 8, 16, 32, 48, 64, 96):
         rng = np.random.default_rng(B * 7 + tmax)
         Tl = rng.integers(200, tmax + 1, B).astype(np.int64); Sl = np.maximum(1, Tl // 25)
         lp, tk = synth.c4_utterances(np.arange(B), Tl, Sl, 67, 1004, dev)
