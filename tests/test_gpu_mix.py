@@ -111,3 +111,27 @@ def test_mixed_call_of_long_paths_only(ora, gpu_device):
                 bad = np.nonzero(st != exp["status"])[0]
                 assert bad.size == 0, [(int(T_len[b]), int(S_len[b]), int(st[b])) for b in bad[:12]]
                 _compare(res, exp, T_len)
+
+
+def test_small_mixed_calls(ora, gpu_device):
+    """calls of 2 ... 40 utterances of different lengths (the process_sentences_batch regime) take the mixed-length path too, with
+    the consumers' band masks computed in lanes (k_mix<.., LM>, calls of <= 256 utterances): BASELINE config 4's generator
+    incl. utterances that die on the way (closed form under the lane masks), flat posteriors, both final-state rules, host hint
+    and the library's own class choice"""
+    from tools import synth
+    Tl, Sl = synth.c4_lengths(32768)
+    by_len = np.argsort(Tl)
+    for B in (2, 3, 7, 40):
+        pick = np.concatenate([by_len[-(B // 2):], by_len[::(32768 // (B - B // 2))][:B - B // 2]])
+        lp, tk = synth.c4_utterances(pick, Tl[pick], Sl[pick], 67, 1004, "cpu")
+        lp, tk = lp.numpy(), tk.numpy().astype(np.int64)
+        for tf in (True, False):
+            for hint in (0, None):
+                res, exp = _run(ora, gpu_device, lp, tk, Tl[pick], Sl[pick], 67, tf, class_mask=hint)
+                _compare(res, exp, Tl[pick])
+    rng = np.random.default_rng(9500)
+    shapes = [(2600, 104), (700, 28), (1500, 60), (401, 100), (90, 25), (40, 40), (10, 30), (300, 12)]
+    lp, tk, T_len, S_len = _batch(rng, 67, 16, shapes, kinds=(0.3, "dying", 9.0, 0.0))
+    for tf in (True, False):
+        res, exp = _run(ora, gpu_device, lp, tk, T_len, S_len, 67, tf)
+        _compare(res, exp, T_len)
