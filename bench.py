@@ -201,6 +201,48 @@ def _union_ms(spans):
     return busy + ((cur_b - cur_a) if cur_b is not None else 0.0)
 
 
+def measured_copy_peak(dev, lib, h, nbytes=1 << 30, reps=12):
+    """The copy ceiling of THIS GPU in this process: a float4 copy kernel of the library (bfa_profile_copy)
+    over 1 GiB (2 GiB of HBM traffic per launch), HIP events on the launch stream; the best and the mean of `reps` launches."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    src.random_(0, 255)
+    st = torch.cuda.current_stream(dev)
+    for _ in range(3):
+        lib.bfa_profile_copy(h, dst.data_ptr(), src.data_ptr(), nbytes, st.cuda_stream)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        lib.bfa_profile_copy(h, dst.data_ptr(), src.data_ptr(), nbytes, st.cuda_stream)
+        e1.record(st)
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    ok = bool(torch.equal(src[:1 << 20], dst[:1 << 20]) and torch.equal(src[-(1 << 20):], dst[-(1 << 20):]))
+    del src, dst
+    return {"gbs_best": 2 * nbytes / (min(ms) * 1e-3) / 1e9, "gbs_mean": 2 * nbytes / (float(np.mean(ms)) * 1e-3) / 1e9,
+            "bytes_moved_per_launch": 2 * nbytes, "launches": reps, "copied_correctly": ok}
+
+
+def k1_valu_from_pmc(kernel_prefix="k_dp4w<2, 4, 3"):
+    """SQ_INSTS_VALU of the headline K1 per launch from the newest committed PMC summary (tools/pmc.sh format)."""
+    for name in ("r05_headline_pmc.txt", "r04_headline_pmc.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        cur = None
+        for ln in open(path):
+            if not ln.startswith(" "):
+                cur = ln.strip()
+            elif cur and cur.startswith(kernel_prefix) and ln.split()[0] == "SQ_INSTS_VALU":
+                return float(ln.split()[1]), name
+    return None, None
+
+
+N_SIMD, SIMD_CLOCK_HZ = 1024, 2.4e9   # MI355X: 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+
+
 def headline_main(args, rk):
     from bournemouth_forced_aligner_amd import BatchesInFlight, calculate_confidences_batch, _lib
     from bournemouth_forced_aligner_amd.sharding import gather_results
@@ -386,17 +428,20 @@ def headline_main(args, rk):
     # final gather of the (small) result records over RCCL, outside the timed steps
     gather_ms = None
     if dist is not None:
-        gidx = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int64)
-        gather_results(res.segs, res.seg_count, conf, gidx, world * B)  # warm (communicator set-up)
+        # every rank holds B utterances of <= S tuples: the record bounds need no exchange
+        gidx = torch.arange(rank * B, (rank + 1) * B, dtype=torch.int32, device=dev)
+        gkw = dict(n_cap=B, tuple_cap=B * res.segs.shape[1])
+        gather_results(res.segs, res.seg_count, conf, gidx, world * B, **gkw)  # warm (communicator set-up)
         torch.cuda.synchronize()
         rk.barrier()
         g0 = time.perf_counter()
-        out = gather_results(res.segs, res.seg_count, conf, gidx, world * B)
+        out = gather_results(res.segs, res.seg_count, conf, gidx, world * B, **gkw)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            gs, gc, _gf = out
-            assert gs.shape[0] == world * B and torch.equal(gs[:B, :res.segs.shape[1]], res.segs) \
+            gs, gc, _gf = out.to_padded(res.segs.shape[1])
+            k = torch.arange(res.segs.shape[1], device=dev)[None, :] < res.seg_count[:, None]
+            assert gs.shape[0] == world * B and torch.equal(gs[:B][k], res.segs[k]) \
                 and torch.equal(gc[:B], res.seg_count), "gathered records differ from rank 0's own results"
 
     frames_per_step = B * T
@@ -425,6 +470,16 @@ def headline_main(args, rk):
             traffic, tfile = json.load(open(tpath))["traffic_bytes_per_launch"], name
             break
 
+    copy_peak = measured_copy_peak(dev, lib, hs[0]) if rank == 0 else None
+    valu_insts, valu_file = k1_valu_from_pmc() if (B, T, S, C) == (4096, 1000, 40, 67) else (None, None)
+    valu = None
+    if valu_insts and nk:
+        floor_ms = valu_insts / (N_SIMD * SIMD_CLOCK_HZ / 4) * 1e3
+        valu = {"insts_per_launch": valu_insts, "source": f"SQ_INSTS_VALU, rocprofv3 PMC, profiles/{valu_file}",
+                "insts_per_frame": valu_insts / frames_per_step, "issue_floor_ms": floor_ms,
+                "issue_floor_what": f"insts / ({N_SIMD} SIMDs x {SIMD_CLOCK_HZ / 1e9:g} GHz / 4 cycles per wave64 instruction)",
+                "kernel_over_floor": kernel_ms / floor_ms}
+
     ranks = rk.describe()
     if rank == 0:
         kname = "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer)" if (B, T, S, C) == (4096, 1000, 40, 67) \
@@ -432,6 +487,8 @@ def headline_main(args, rk):
         line = {
             "metric": "aligned frames/sec (whole node) on ph66 posteriors", "value": value,
             "unit": "aligned frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "timed_steps_total": total_steps,
+            "timed_steps_what": f"{n_windows} windows of exactly --steps {K} steps are timed; ms_per_step = their total time / {total_steps}",
             "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch={B} T={T} |tokens|={S} ph66 (C={C}) per GPU, reference-default flags "
@@ -454,6 +511,12 @@ def headline_main(args, rk):
                        "host_issue_ms_per_step": float(np.sum(issue_t)) / total_steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "measured_copy_peak": copy_peak["gbs_best"] if copy_peak else None,
+                         "measured_copy_peak_what": "float4 copy kernel over 1 GiB in this process (bfa_profile_copy), read + "
+                                                    "written bytes / best of 12 launches; the data-sheet peak is `peak`",
+                         "measured_copy": copy_peak,
+                         "frac_of_measured": (achieved / copy_peak["gbs_best"]) if (achieved and copy_peak) else None,
+                         "valu": valu,
                          "traffic_unit": f"bytes per K1 launch (rocprofv3 PMC, profiles/{tfile})" if tfile else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_frame": bytes_per_frame,
                          "kernel": kname,
@@ -572,6 +635,15 @@ def c4_plan(n_total, world, seed, chunk, halves=1):
     return T, S, shards, plans, loads
 
 
+def c4_record_bounds(shards, S, cap, extra=0):
+    """(n_cap, tuple_cap) of the packed result records, the same on every rank WITHOUT an exchange: every rank knows the
+    partition, an utterance of S tokens yields at most min(S, cap) tuples (ignore_noise: blank runs are not emitted,
+    forced_alignment.py:822-831) plus `extra` rows the bench lets ride along."""
+    n_cap = max(len(s) for s in shards)
+    tuple_cap = max(int((np.minimum(S[s], cap) + extra).sum()) for s in shards)
+    return max(n_cap, 1), max(tuple_cap, 1)
+
+
 def c4_main(args, rk):
     dev, rank, world, dist = rk.dev, rk.rank, rk.world, rk.dist
     C, seed, n_total = args.classes, args.seed, args.global_batch
@@ -594,10 +666,11 @@ def c4_main(args, rk):
         segs = torch.zeros((len(mine), cap, 4), dtype=torch.int32)
         segs[:, 0, 0] = torch.from_numpy(mine).to(torch.int32)
         cnt = torch.from_numpy(np.minimum(S[mine], cap)).to(torch.int32)
-        out = gather_results(segs, cnt, None, torch.from_numpy(mine), n_total)
+        n_cap, tuple_cap = c4_record_bounds(shards, S, cap, extra=0)
+        out = gather_results(segs, cnt, None, torch.from_numpy(mine), n_total, n_cap=n_cap, tuple_cap=tuple_cap)
         ok = None
         if rank == 0:
-            gs, gc, _ = out
+            gs, gc, _ = out.to_padded(cap)
             ok = bool(torch.equal(gs[:, 0, 0].long(), torch.arange(n_total)) and
                       np.array_equal(gc.numpy(), np.minimum(S, cap)))
         ranks = rk.describe()
@@ -703,32 +776,47 @@ def c4_main(args, rk):
 
     # ---- final gather of the result records (outside the steps; timed on its own, after a warm-up gather that
     # pays for the communicator set-up)
-    segs = torch.cat([r.segs for r in res], 0)
-    cnt = torch.cat([r.seg_count for r in res], 0)
-    gidx = torch.from_numpy(np.concatenate([c["idx"] for c in chunks]))
+    segs = torch.cat([r.segs for r in res], 0) if len(res) > 1 else res[0].segs
+    cnt = torch.cat([r.seg_count for r in res], 0) if len(res) > 1 else res[0].seg_count
+    gidx = torch.from_numpy(np.concatenate([c["idx"] for c in chunks]).astype(np.int32)).to(dev)
     csum = torch.cat([c["csum"] for c in chunks], 0)
-    # the input checksum rides along as two int32 "segments" in a spare row (cap + 1 rows)
-    segs_x = torch.zeros((segs.shape[0], cap + 1, 4), dtype=torch.int32, device=dev)
-    segs_x[:, :cap] = segs
+    # the input checksum rides along as one more "tuple" behind each utterance's own (row count[b] < cap is free)
     cs62 = csum & ((1 << 62) - 1)
-    segs_x[:, cap, 0] = (cs62 & ((1 << 31) - 1)).to(torch.int32)
-    segs_x[:, cap, 1] = (cs62 >> 31).to(torch.int32)
-    gather_results(segs_x, cnt, None, gidx, n_total)
+    rows = torch.arange(segs.shape[0], device=dev)
+    segs[rows, cnt.long(), 0] = (cs62 & ((1 << 31) - 1)).to(torch.int32)
+    segs[rows, cnt.long(), 1] = (cs62 >> 31).to(torch.int32)
+    cnt_x = cnt + 1
+    # record bounds every rank derives from the partition it already knows: no size exchange
+    n_cap, tuple_cap = c4_record_bounds(shards, S, cap, extra=1)
+    gkw = dict(n_cap=n_cap, tuple_cap=tuple_cap)
+    gather_results(segs, cnt_x, None, gidx, n_total, **gkw)
     torch.cuda.synchronize()
-    rk.barrier()
-    g0 = time.perf_counter()
-    out = gather_results(segs_x, cnt, None, gidx, n_total)
-    torch.cuda.synchronize()
-    gather_ms = (time.perf_counter() - g0) * 1e3
-    gather_ms, _ = rk.max_over_ranks(gather_ms)
+    gms = []
+    for _ in range(5):
+        rk.barrier()
+        g0 = time.perf_counter()
+        out = gather_results(segs, cnt_x, None, gidx, n_total, **gkw)   # one pack kernel + one collective
+        torch.cuda.synchronize()
+        gms.append((time.perf_counter() - g0) * 1e3)
+    gather_ms, _ = rk.max_over_ranks(float(np.median(gms)))
+    index_ms = host_ms = payload = None
+    if rank == 0:
+        g0 = time.perf_counter()
+        out.index()                                                        # one kernel: (owner, offset, count) per utterance
+        torch.cuda.synchronize()
+        index_ms = (time.perf_counter() - g0) * 1e3
+        g0 = time.perf_counter()
+        out.host()                                                         # the records on the host (pageable memory)
+        host_ms = (time.perf_counter() - g0) * 1e3
+        payload = int(out.records.numel() * 4)
+        assert not out.overflowed(), "a rank's tuples did not fit the agreed record bound"
 
     total_frames = int(T.sum())
     total_bytes = int(((4 * C + (4 * S + 1 + 3) // 4 + 8) * T).sum())
     step_s = elapsed / args.steps
     parity = None
     if rank == 0:
-        gs, gc, _ = out
-        parity = c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed)
+        parity = c4_parity_sample(args, T, S, out, cap, dev, C, seed)
     ranks = rk.describe()
     if rank == 0:
         line = {
@@ -748,6 +836,10 @@ def c4_main(args, rk):
             "frames_per_step": total_frames,
             "value_with_gather": total_frames / (step_s + gather_ms * 1e-3),
             "gather_ms": gather_ms,
+            "gather": {"what": "bfa_pack_results (one kernel) + one torch.distributed.gather of equal-size packed records; "
+                               "median of 5, max over ranks; the receiver keeps the records as they arrive",
+                       "payload_bytes": payload, "record_bounds": {"n_cap": n_cap, "tuple_cap": tuple_cap},
+                       "index_ms": index_ms, "records_to_host_ms": host_ms},
             "rank_ms_per_step": rank_ms,
             "rank_ms_max_over_mean": float(max(rank_ms) / np.mean(rank_ms)),
             "planned_load_max_over_mean": float(loads.max() / loads.mean()),
@@ -765,7 +857,7 @@ def c4_main(args, rk):
         print(json.dumps(line))
 
 
-def c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed):
+def c4_parity_sample(args, T, S, out, cap, dev, C, seed):
     """Rank 0, after the gather: a stratified sample (every length stratum + the 32 longest utterances) is synthesised
     again from the global indices, its input checksum compared with the one the owning rank gathered, and the
     gathered records compared with the oracle's."""
@@ -779,8 +871,6 @@ def c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed):
     prm = ora.make_params(C - 1, 0)
     mism, bad_inputs, frames = 0, 0, 0
     w = 0.0
-    gs_h = gs.cpu().numpy()
-    gc_h = gc.cpu().numpy()
     for i in range(0, len(sample), 64):
         sub = sample[i:i + 64]
         lp, tk = c4_utterances(sub, T[sub], S[sub], C, seed, dev)
@@ -791,11 +881,12 @@ def c4_parity_sample(args, T, S, gs, gc, cap, dev, C, seed):
         w += time.perf_counter() - w0
         for k, g in enumerate(sub):
             frames += int(T[g])
-            got_cs = int(gs_h[g, cap, 0]) + (int(gs_h[g, cap, 1]) << 31)
+            rows, _ = out.rows(int(g))   # the utterance's tuples + the checksum row, from the packed records
+            got_cs = int(rows[-1, 0]) + (int(rows[-1, 1]) << 31)
             if got_cs != int(cs[k]) & ((1 << 62) - 1):
                 bad_inputs += 1
             c = int(exp["seg_count"][k])
-            if int(gc_h[g]) != c or not (gs_h[g, :c] == exp["seg"][k, :c]).all():
+            if rows.shape[0] - 1 != c or not (rows[:c] == exp["seg"][k, :c]).all():
                 mism += 1
     return {"utterances": int(len(sample)), "frames": frames, "longest_T": int(T[sample].max()),
             "mismatching_utterances": mism, "regenerated_inputs_differing": bad_inputs,
@@ -1028,7 +1119,8 @@ def dry_headline(args, rk):
     segs[:, 0, 0] = gidx.to(torch.int32)
     cnt = torch.full((B,), 1, dtype=torch.int32)
     if rk.dist is not None:
-        out = gather_results(segs, cnt, None, gidx, rk.world * B)
+        out = gather_results(segs, cnt, None, gidx, rk.world * B, n_cap=B, tuple_cap=B)
+        out = out.to_padded(cap) if rk.rank == 0 else None
     else:
         out = (segs, cnt, None)
     ranks = rk.describe()

@@ -16,13 +16,16 @@ HINT_NO_SILENCE_TARGETS = 1 << 16
 HINT_UNIFORM_LENGTHS = 1 << 17
 OPT_CALLS_IN_FLIGHT = 1  # bfa_set_option: the caller keeps several bfa_align_heads calls in flight (BatchesInFlight)
 MIX_MIN_BATCH = 2   # bfa_types.hpp: calls of at least this many utterances with non-uniform lengths take the one-kernel mixed path (k_mix)
+ONE_HINT_MAX_BATCH = 64  # forced_alignment.hint_and_path asks for the one-kernel path below this many utterances
 ONE_MAX_BATCH = 1024  # bfa_types.hpp: calls of at most this many utterances in ONE fast-window class take the one-kernel path of small calls (k_one)
+PATH_CLASS_KERNELS, PATH_MIXED, PATH_ONE_KERNEL = 0, 1, 2  # bfa_call_path
 MODE_EMPTY, MODE_SEGMENTED, MODE_STANDARD, MODE_PROPORTIONAL = 0, 1, 2, 3
 
 EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_last_error",
            "bfa_params_default", "bfa_workspace_bytes", "bfa_align_batch", "bfa_confidences",
            "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
-           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_profile_collect_spans", "bfa_set_option"]
+           "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_profile_collect_spans", "bfa_set_option",
+           "bfa_pack_words", "bfa_pack_results", "bfa_index_records", "bfa_call_path", "bfa_profile_copy"]
 
 
 class BfaParams(ctypes.Structure):
@@ -95,6 +98,12 @@ def lib():
     L.bfa_set_option.argtypes = [vp, i32, i32]
     L.bfa_profile_collect_spans.argtypes = [vp, vp, vp, vp, i32]
     L.bfa_profile_collect.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32]
+    L.bfa_call_path.argtypes = [i32, i32, i32, i32, ctypes.POINTER(BfaParams), i32]
+    L.bfa_profile_copy.argtypes = [vp, vp, vp, sz, vp]
+    L.bfa_pack_words.argtypes = [i32, i64, i32]
+    L.bfa_pack_words.restype = i64
+    L.bfa_pack_results.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.bfa_index_records.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -209,20 +209,24 @@ class PhonemeTimestampAligner:
             res.segs.copy_(torch.from_numpy(host))
             res.seg_count.copy_(torch.tensor([len(rs) for rs in rows], dtype=torch.int32))
             estimated = [[bool(r[4]) for r in rs] for rs in rows]
-        if res.conf is not None:  # the fused call already ran coverage / soft boundaries / confidences on the head's stream
+        if res.postprocessed and res.conf is not None:  # the fused call already ran coverage / soft boundaries / confidences on the head's stream
             return res, res.conf, res.conf_status, estimated
-        postprocess_batch(log_probs, seq_lens, res.segs, res.seg_count, extend=self.extend_soft_boundaries,
-                          boundary_softness=self.boundary_softness, row_stats=stats)
+        if not res.postprocessed:  # (a result that only carries confidences -- BatchesInFlight.submit(confidences=True) -- still needs the stages)
+            postprocess_batch(log_probs, seq_lens, res.segs, res.seg_count, extend=self.extend_soft_boundaries,
+                              boundary_softness=self.boundary_softness, row_stats=stats)
+            res.postprocessed = True
         conf, cstat = calculate_confidences_batch(log_probs, res.segs, res.seg_count, row_stats=stats)  # padded rows (core.py:936)
         return res, conf, cstat, estimated
 
     def extract_timestamps_from_logits(self, logits_class, logits_group, spectral_lens, phoneme_sequences, wav_lens,
                                        start_offset_times=0, group_sequences=None, do_groups=True, as_arrays=False,
-                                       fused=True):
+                                       fused=True, lazy=False):
         """core.py:897-964 given the model's logits.  Returns list[B] of dicts with 'phoneme_timestamps' and
         'group_timestamps': lists of (id, start_frame, end_frame, target_seq_idx, is_estimated, confidence,
         start_ms, end_ms).  With `as_arrays` the same data as padded numpy arrays per head ({'rows' [B,cap,4],
-        'count' [B], 'is_estimated', 'confidence', 'start_ms', 'end_ms' [B,cap]}) for bulk consumers."""
+        'count' [B], 'is_estimated', 'confidence', 'start_ms', 'end_ms' [B,cap]}) for bulk consumers; with `lazy` a
+        LazyRowDicts that builds an utterance's dict and tuples when it is looked at (neither flag is in the reference;
+        the default is the reference's plain list of dicts of lists of tuples)."""
         dev = self.device
         B = logits_class.shape[0]
         if isinstance(phoneme_sequences, torch.Tensor):
@@ -274,7 +278,10 @@ class PhonemeTimestampAligner:
             arrays[key] = self._shape_rows(res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays)
         # (the reference returns a list of B dicts of lists of 8-tuples: here that list builds an utterance's dict and tuples
         # when it is looked at -- 327 680 tuples of the headline batch cost CPython ~85 ms whoever builds them)
-        return arrays if as_arrays else LazyRowDicts(arrays, B)
+        if as_arrays:
+            return arrays
+        out = LazyRowDicts(arrays, B)
+        return out if lazy else out.tolist()
 
     def _shape_rows(self, res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays):
         """core.py:939-956 for one head and the whole batch at once: convert_to_ms in the float32 tensor arithmetic

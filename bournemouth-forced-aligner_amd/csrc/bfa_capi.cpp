@@ -30,6 +30,12 @@ extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t 
                                    const int32_t *S_len, bfa_segment *segs, int seg_cap, int32_t *seg_count, int do_post,
                                    int extend, double th1, double th2, int do_conf, const int32_t *T_rows, float *conf,
                                    int32_t *status, void *stream);
+extern "C" int bfa_launch_pack(const int32_t *segs, int seg_cap, const int32_t *seg_count, const float *conf, const int32_t *gidx,
+                               int gidx_base, int n, int n_cap, int tuple_cap, int32_t *out, void *stream);
+extern "C" int bfa_launch_index_records(const int32_t *rec, int world, int64_t words, int n_max, int n_total, int32_t *owner,
+                                        int32_t *offset, int32_t *count, void *stream);
+extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *p);
+extern "C" int bfa_launch_copy(void *dst, const void *src, size_t bytes, void *stream);
 static bool staged_post() { return true; } // k_postconf whenever the shapes fit its LDS budget (the tuple-per-lane kernels otherwise)
 
 struct bfa_context {
@@ -73,6 +79,22 @@ struct Carve {
         return p;
     }
 };
+
+bfa::DevParams to_dev_params(const bfa_params *params, bool has_T_len)
+{
+    bfa::DevParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.blank = params->blank_id; p.sil = params->silence_id; p.anchors = params->silence_anchors;
+    p.ignore_noise = params->ignore_noise; p.truly_forced = params->truly_forced;
+    p.boost = params->boost_targets; p.enforce = params->enforce_minimum; p.simple = params->simple;
+    p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
+    p.class_mask = (uint32_t)params->class_mask; p.win_mask = 0;
+    if (!has_T_len) p.class_mask |= (uint32_t)BFA_HINT_UNIFORM_LENGTHS; // every utterance has Tmax frames
+    p.win_max_tokens = params->window_max_tokens > 0 ? params->window_max_tokens : bfa::WIN_MAX_TOKENS;
+    p.win_max_frames = params->window_max_frames > 0 ? params->window_max_frames : bfa::WIN_MAX_FRAMES;
+    p.min_logp = params->has_min_log_prob ? params->min_log_prob : bfa::MIN_LOGP;
+    return p;
+}
 
 bool segmented_possible(const bfa_params *p)
 {
@@ -323,6 +345,9 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
     if (params->blank_id < 0 || params->blank_id >= C)
         return fail(h, BFA_ERR_INVALID_ARGUMENT, "Blank ID not set"); // forced_alignment.py:104-105
     if (strideT < C) return fail(h, BFA_ERR_INVALID_ARGUMENT, "strideT < C");
+    // grids over (utterance, 64-frame segment) units must fit a launch (the exact window's tail kernel, bfa_dp4.inc); such a
+    // batch would hold > 10^11 posterior rows
+    if ((int64_t)B * ((Tmax + 63) / 64) > 0x7fffffffll) return fail(h, BFA_ERR_UNSUPPORTED, "B x Tmax / 64 exceeds a launch grid");
     if ((out_frame_phoneme == nullptr) != (out_frame_idx == nullptr))
         return fail(h, BFA_ERR_INVALID_ARGUMENT, "frame outputs must both be given or both be NULL");
 
@@ -353,14 +378,7 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
     }
     a.B = B; a.Tmax = Tmax; a.C = C; a.Smax = Smax;
     a.T_len = T_len; a.tokens = tokens; a.S_len = S_len;
-    a.p.blank = params->blank_id; a.p.sil = params->silence_id; a.p.anchors = params->silence_anchors;
-    a.p.ignore_noise = params->ignore_noise; a.p.truly_forced = params->truly_forced;
-    a.p.boost = params->boost_targets; a.p.enforce = params->enforce_minimum; a.p.simple = params->simple;
-    a.p.max_blanks = params->max_blanks > 0 ? params->max_blanks : 10;
-    a.p.class_mask = (uint32_t)params->class_mask; a.p.win_mask = 0;
-    a.p.win_max_tokens = params->window_max_tokens > 0 ? params->window_max_tokens : bfa::WIN_MAX_TOKENS;
-    a.p.win_max_frames = params->window_max_frames > 0 ? params->window_max_frames : bfa::WIN_MAX_FRAMES;
-    a.p.min_logp = params->has_min_log_prob ? params->min_log_prob : bfa::MIN_LOGP;
+    a.p = to_dev_params(params, T_len != nullptr);
     if (a.p.min_logp != a.p.min_logp) return fail(h, BFA_ERR_INVALID_ARGUMENT, "min_log_prob is NaN");
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
@@ -557,6 +575,50 @@ int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out
     if (C < 2 || C > bfa::MAX_C) return fail(h, BFA_ERR_UNSUPPORTED, "C must be in [2,128]");
     if (rows == 0) return BFA_OK;
     const int rc = bfa_launch_log_softmax(logits, ld_in, out, ld_out, rows, C, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_call_path(int B, int Tmax, int Smax, int C, const bfa_params *params, int has_T_len)
+{
+    (void)Tmax;
+    if (!params || B <= 0 || Smax <= 0 || C < 2) return BFA_ERR_INVALID_ARGUMENT;
+    const bfa::DevParams p = to_dev_params(params, has_T_len != 0);
+    return bfa_call_path_impl(B, C, Smax, &p);
+}
+
+int bfa_profile_copy(bfa_handle h, void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
+    if (!dst || !src || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "dst / src / bytes must be 16-byte multiples");
+    const int rc = bfa_launch_copy(dst, src, bytes, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_pack_results(bfa_handle h, const bfa_segment *segs, int seg_cap, const int32_t *seg_count, const float *conf,
+                     const int32_t *global_index, int gidx_base, int n, int n_cap, int tuple_cap, int32_t *out, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
+    if (!out || n < 0 || n_cap < n || tuple_cap < 0 || seg_cap < 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n > 0 && (!segs || !seg_count)) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (((uintptr_t)out & 15) || ((uintptr_t)segs & 15)) return fail(h, BFA_ERR_INVALID_ARGUMENT, "segs / out must be 16-byte aligned");
+    const int rc = bfa_launch_pack((const int32_t *)segs, seg_cap, seg_count, conf, global_index, gidx_base, n, n_cap, tuple_cap, out, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_index_records(bfa_handle h, const int32_t *records, int world, int64_t words, int n_max, int n_total,
+                      int32_t *out_owner, int32_t *out_offset, int32_t *out_count, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
+    if (!records || !out_owner || !out_offset || !out_count || world <= 0 || world > 65535 || words < 8 || n_total < 0 || n_max < 0)
+        return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");
+    const int rc = bfa_launch_index_records(records, world, words, n_max, n_total, out_owner, out_offset, out_count, stream);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }

@@ -243,16 +243,23 @@ extern "C" void bfa_k1_one_nk5(const bfa::AlignArgs *a, int RW, hipStream_t s);
 extern "C" void bfa_k1_mix_nk2(const bfa::AlignArgs *a, const int32_t *order, hipStream_t s);
 extern "C" void bfa_k1_mix_nk5(const bfa::AlignArgs *a, const int32_t *order, hipStream_t s);
 
-extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void *fork_event, int naux)
+namespace bfa {
+
+// Which kernels a call takes, from its shapes and the caller's hints alone (host arithmetic; bfa_call_path reports it):
+// the per-class kernels side by side, the one-kernel mixed-length path (k_mix) or the one-kernel path of small single-class
+// calls (k_one).
+struct CallPlan {
+    int mode;            // 0 reference-default flags without silence anchoring, 1 with, 2 other flags (no fused preparation)
+    unsigned mask;       // class kernels that may find items: bits 0-6 full layouts, 8-15 fast windows, 20-27 exact windows
+    unsigned wmask, wall, xmask;
+    bool hinted, seg_possible, one_ok, use_mix;
+    int rw1;
+};
+
+static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frames)
 {
-    using namespace bfa;
-    hipStream_t stream = (hipStream_t)stream_;
-    AlignArgs a = *args;
-    const DevParams &p = a.p;
-    const int nk = (a.C + 15) / 16;
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
-    const int Lmax = 4 * a.Smax + 1;
+    const int Lmax = 4 * Smax + 1;
     unsigned mask = r_class_mask_upto(Lmax);
     const bool hinted = ((unsigned)p.class_mask & 0x0ff0ffffu) != 0u; // a class selection (flag bits alone are not one)
     if (hinted) mask &= (unsigned)p.class_mask & 0xffffu;
@@ -260,7 +267,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const int mode = (p.boost && p.enforce && !p.simple) ? (seg_possible ? 1 : 0) : 2;
     // sliding-window classes (16-rows-per-pass kernels only: reference-default flags, C = 67 or 17)
     unsigned wmask = 0, wall = 0;
-    if (mode != 2 && (a.C == 67 || a.C == 17) && Lmax > 60) {
+    if (mode != 2 && (C == 67 || C == 17) && Lmax > 60) {
         wmask = 0xafu; // Rw in {1,2,3,4,6,8} (bit Rw-1); classes no utterance can use cost one empty launch each
         const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
         for (int rw = 8; rw >= 1; --rw) // drop the classes above the one the longest possible path would take
@@ -274,7 +281,6 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // the window consumers in the mode's merged K1 kernel cost every PIECE 30 spilled VGPRs (one 256-byte scratch store per
     // item and spilled register: 0.29 GB of DRAM writes per 4096-utterance launch; realtext 1.54 -> 1.49 ms per step).
     if (seg_possible) wmask = 0;
-    a.p.win_mask = wmask;
     mask |= wmask << 8;
     // Exact-window classes (bfa_dp3.inc: DpCoreW<.., EX>): banded standard-mode items the fast window is not tried on -- too
     // many frames or tokens for a result that only stands above the sentinel -- compute their in-band states only, too,
@@ -288,17 +294,47 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // (a small call the hint puts in ONE fast-window class is k_one's, see below)
     const unsigned hw1 = (p.class_mask >> 8) & 0xffu;
     const int rw1 = (hw1 == 1u) ? 1 : (hw1 == 2u) ? 2 : (hw1 == 4u) ? 3 : 0;
-    const bool one_ok = !seg_possible && mode == 0 && (a.C == 67 || a.C == 17) && rw1 > 0 && (p.class_mask & 0x7fu) == 0 &&
-                        ((p.class_mask >> 20) & 0xffu) == 0 && ((wmask >> (rw1 > 0 ? rw1 - 1 : 0)) & 1u) && a.B <= ONE_MAX_BATCH && Lmax <= 256 &&
-                        a.frame_ph && a.frame_idx;
-    const bool use_mix = mode == 0 && !seg_possible && (a.C == 67 || a.C == 17) && wall != 0 && a.B >= MIX_MIN_BATCH && !one_ok &&
-                         !(p.class_mask & BFA_HINT_UNIFORM_LENGTHS) && a.frame_ph && a.frame_idx;
+    const bool one_ok = !seg_possible && mode == 0 && (C == 67 || C == 17) && rw1 > 0 && (p.class_mask & 0x7fu) == 0 &&
+                        ((p.class_mask >> 20) & 0xffu) == 0 && ((wmask >> (rw1 > 0 ? rw1 - 1 : 0)) & 1u) && B <= ONE_MAX_BATCH && Lmax <= 256 &&
+                        frames;
+    const bool use_mix = mode == 0 && !seg_possible && (C == 67 || C == 17) && wall != 0 && B >= MIX_MIN_BATCH && !one_ok &&
+                         !(p.class_mask & BFA_HINT_UNIFORM_LENGTHS) && frames;
     if (use_mix) {
         const unsigned narrow_x = hinted ? (wall & (((unsigned)p.class_mask >> 20) | ((unsigned)p.class_mask >> 8)) & 0xfu) : (wall & 0xfu);
         xmask |= narrow_x | XWIN_MIX;
     }
-    a.p.xwin_mask = xmask;
     mask |= (xmask & 0xafu) << 20;
+    CallPlan c;
+    c.mode = mode; c.mask = mask; c.wmask = wmask; c.wall = wall; c.xmask = xmask; c.hinted = hinted;
+    c.seg_possible = seg_possible; c.one_ok = one_ok && (xmask & 0xafu) == 0; c.use_mix = use_mix; c.rw1 = rw1;
+    return c;
+}
+
+} // namespace bfa
+
+// 0: per-class kernels, 1: k_mix (+ class kernels for what it has no body for), 2: k_one
+extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *p)
+{
+    const bfa::CallPlan c = bfa::plan_call(B, C, Smax, *p, true);
+    return c.one_ok ? 2 : (c.use_mix ? 1 : 0);
+}
+
+extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
+                                void **aux_streams, void **aux_events, void *fork_event, int naux)
+{
+    using namespace bfa;
+    hipStream_t stream = (hipStream_t)stream_;
+    AlignArgs a = *args;
+    const DevParams &p = a.p;
+    const int nk = (a.C + 15) / 16;
+    const CallPlan cp = plan_call(a.B, a.C, a.Smax, p, a.frame_ph && a.frame_idx);
+    const int Lmax = 4 * a.Smax + 1;
+    unsigned mask = cp.mask;
+    const unsigned wmask = cp.wmask, xmask = cp.xmask;
+    const bool seg_possible = cp.seg_possible, use_mix = cp.use_mix;
+    const int mode = cp.mode, rw1 = cp.rw1;
+    a.p.win_mask = wmask;
+    a.p.xwin_mask = xmask;
     // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
     // class right behind its K1 kernel on that kernel's stream, the window classes after the sentinel reruns, and
     // emits the run-length tuples during the walk -- no K3a launch.
@@ -311,7 +347,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     a.xcd_contig = (mode == 0 && (p.class_mask & BFA_HINT_UNIFORM_LENGTHS)) ? 1 : 0;
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
-    if (one_ok && (xmask & 0xafu) == 0) {
+    if (cp.one_ok) {
         a.p.xwin_mask = 0; // (k_one reruns its own window failures with the full layout)
         if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
         if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);

@@ -195,6 +195,7 @@ class AlignmentResult:
         self.S_len = S_len
         self.conf = None         # float32 [B, seg_cap] / int32 [B]: only when the call also ran the post-DP stages
         self.conf_status = None  # (align_heads(post=...))
+        self.postprocessed = False  # coverage / soft boundaries already ran in place on segs / seg_count (they are not idempotent)
 
     def raise_for_status(self):
         """Reproduce the reference's exceptions (they abort the whole call)."""
@@ -221,13 +222,17 @@ class AlignmentResult:
 
     def to_lists(self):
         """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871).
-        One device-side compaction of the valid rows, ONE copy to the host, one flat list of tuples cut per utterance
-        (a per-utterance `.tolist()` loop cost 76 ms on the 4096-utterance headline batch against 0.35 ms of device time)."""
-        cnt_d = self.seg_count
-        cap = self.segs.shape[1]
-        valid = torch.arange(cap, device=cnt_d.device, dtype=torch.int32).unsqueeze(0) < cnt_d.clamp(max=cap).unsqueeze(1)
-        packed = self.segs[valid].cpu().numpy()         # [sum(count), 4] in utterance order
-        cnt = cnt_d.clamp(max=cap).cpu().numpy()
+        ONE kernel packs the valid rows back to back (bfa_pack_results), two copies bring them to the host (the count table,
+        then exactly the packed tuples), one flat list of tuples is cut per utterance (a per-utterance `.tolist()` loop cost
+        76 ms on the 4096-utterance headline batch against 0.35 ms of device time)."""
+        from .sharding import pack_layout, pack_results
+        n, cap = int(self.segs.shape[0]), int(self.segs.shape[1])
+        rec = pack_results(self.segs, self.seg_count, None, None, n, n * cap)
+        lay = pack_layout(n, n * cap, False)
+        head = rec[:lay["tuples"]].cpu().numpy()
+        total = int(head[1])
+        cnt = head[lay["count"]:lay["count"] + n]
+        packed = rec[lay["tuples"]:lay["tuples"] + 4 * total].cpu().numpy()
         return LazyRowLists(packed.view(_ROW4).reshape(-1), cnt)
 
 
@@ -308,7 +313,15 @@ class ViterbiDecoder:
 
     def class_mask_hint(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
                         boost_targets=True, enforce_minimum=True):
-        """Optional host-side hint for bfa_params.class_mask: the K1 kernel classes that occur in this batch,
+        """bfa_params.class_mask for a batch, from HOST copies of its lengths (see hint_and_path for the rules)."""
+        return self.hint_and_path(T_lens, S_lens, has_sil, anchor_pauses, simple, n_classes, boost_targets, enforce_minimum)[0]
+
+    def hint_and_path(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
+                      boost_targets=True, enforce_minimum=True, Smax=None):
+        """(class_mask, path): the hint and the launch layout it is written for (_lib.PATH_*; the library's own decision
+        for the same shapes is bfa_call_path -- tests/test_host_and_abi.py holds the two against each other).  `Smax`: the
+        padded target width the call will pass (default: the longest target).
+        Optional host-side hint for bfa_params.class_mask: the K1 kernel classes that occur in this batch,
         from HOST copies of the lengths.  Bits 0-6: full-layout states-per-lane classes {2,3,4,6,8,12,16};
         bits 8-15: sliding-window classes Rw in {1,2,3,4,6,8} at bit 7+Rw (used for standard-mode DPs whose band is narrower than
         the path, with the reference-default flags on the 67- / 17-class heads; pass `n_classes`); bits 20-27: the EXACT window
@@ -320,7 +333,9 @@ class ViterbiDecoder:
         T = np.asarray(list(T_lens) if not isinstance(T_lens, np.ndarray) else T_lens, dtype=np.int64).reshape(-1)
         S = np.asarray(list(S_lens) if not isinstance(S_lens, np.ndarray) else S_lens, dtype=np.int64).reshape(-1)
         if T.size == 0:
-            return 0
+            return 0, _lib.PATH_CLASS_KERNELS
+        path = _lib.PATH_CLASS_KERNELS
+        Lmax_call = 4 * int(Smax if Smax is not None else max(1, int(S.max()))) + 1   # the launcher's bound (bfa_kernels.hip plan_call)
         window_ok = (n_classes in (67, 17)) and boost_targets and enforce_minimum and not simple
         # a floor above log(1) = 0 (min_phoneme_prob > 1) breaks the window's exactness argument: the library then runs
         # every item with the full layout (bfa_launch_align), so the hint must name the full classes
@@ -361,10 +376,17 @@ class ViterbiDecoder:
             # window item of the classes Rw <= 4 is an exact-window item (k_mix aligns and walks it in one workgroup)
             # (not a small call whose DPs all sit in ONE fast-window class of at most 256 states: that one is k_one's)
             dp_rw = rw[is_dp]
-            one_class = (T.size < 64 and dp_rw.size > 0 and int(dp_rw.min()) == int(dp_rw.max()) and 1 <= int(dp_rw.max()) <= 3
-                         and not bool(exact.any()) and int(L[is_dp].max()) <= 256)
-            if no_seg and T.size >= _lib.MIX_MIN_BATCH and not self._uniform(T) and not one_class:
+            # (the library takes such a call as ONE kernel up to _lib.ONE_MAX_BATCH utterances and 4 * Smax + 1 <= 256 states; the
+            # hint asks for it below ONE_HINT_MAX_BATCH, where it measured faster than k_mix, profiles/r04_latency_mixed.txt)
+            single = (dp_rw.size > 0 and int(dp_rw.min()) == int(dp_rw.max()) and 1 <= int(dp_rw.max()) <= 3
+                      and not bool(exact.any()) and Lmax_call <= 256 and no_seg)
+            one_class = single and T.size < _lib.ONE_HINT_MAX_BATCH
+            mixed = no_seg and T.size >= _lib.MIX_MIN_BATCH and not self._uniform(T) and not one_class and Lmax_call > 60
+            if mixed:
                 exact = exact | ((rw > 0) & (rw <= 4) & (stride >= 3))
+                path = _lib.PATH_MIXED
+            elif single and T.size <= _lib.ONE_MAX_BATCH:  # (a uniform single-class call up to ONE_MAX_BATCH, e.g. BASELINE configs[1])
+                path = _lib.PATH_ONE_KERNEL
             rx = np.where(exact & (stride >= 3) & no_seg, rw, 0)
             rw[exact] = 0
             for r in np.unique(rx[rx > 0]):
@@ -382,7 +404,11 @@ class ViterbiDecoder:
             mask |= _lib.HINT_NO_SILENCE_TARGETS  # the silence-anchored planning kernels are not launched
         if mask and self._uniform(T):
             mask |= _lib.HINT_UNIFORM_LENGTHS     # about the same number of frames everywhere: one contiguous eighth of the batch per XCD
-        return mask
+        if not mask:  # no class of the hint occurs (paths beyond 1024 states, no DP at all): the call goes out unhinted, and
+            # without the no-silence bit the library has to assume silence anchoring whenever the decoder allows it
+            seg = anchor_pauses and self.silence_anchors > 0 and self.silence_id is not None and not simple
+            path = _lib.PATH_CLASS_KERNELS if (seg or not window_ok or Lmax_call <= 60 or T.size < _lib.MIX_MIN_BATCH) else _lib.PATH_MIXED
+        return mask, path
 
     @staticmethod
     def _uniform(T):
@@ -415,9 +441,10 @@ class ViterbiDecoder:
                 tk_host = _host_array(true_seqs)
                 sil = self.silence_id if self.silence_id is not None else -1
                 has_sil = True if tk_host is None else bool((tk_host == sil).any())
-                class_mask = self.class_mask_hint(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil,
-                                                  anchor_pauses=anchor_pauses, simple=simple, n_classes=C,
-                                                  boost_targets=boost_targets, enforce_minimum=enforce_minimum)
+                class_mask = self.hint_and_path(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil,
+                                                anchor_pauses=anchor_pauses, simple=simple, n_classes=C,
+                                                boost_targets=boost_targets, enforce_minimum=enforce_minimum,
+                                                Smax=Smax)[0]
         S_len = _as_i32(true_seqs_lens, dev)
         T_len = _as_i32(pred_lens, dev)
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
@@ -565,8 +592,11 @@ class AlignmentUtils:
                                                 class_mask=class_mask)
 
     def decode_alignments(self, log_probs, true_seqs=None, pred_lens=None, true_seqs_lens=None,
-                          forced_alignment=True, boost_targets=True, enforce_minimum=True, debug=False):
-        """forced_alignment.py:856-910.  Returns list[B] of list[(phoneme_id, start, end, target_seq_idx)]."""
+                          forced_alignment=True, boost_targets=True, enforce_minimum=True, debug=False, lazy=False):
+        """forced_alignment.py:856-910.  Returns list[B] of list[(phoneme_id, start, end, target_seq_idx)] -- a plain list
+        of lists of tuples, like the reference.  `lazy=True` (not in the reference): a LazyRowLists over one packed host
+        array instead, which builds an utterance's tuples when it is looked at (the 163 840 tuples of the headline batch
+        cost CPython 14 ms, forty times the device step)."""
         if not forced_alignment:
             raise NotImplementedError("free decoding (forced_alignment=False) is outside the accelerated path")
         if (true_seqs is None) or (true_seqs_lens is None):
@@ -574,9 +604,10 @@ class AlignmentUtils:
         res = self.decode_alignments_device(log_probs, true_seqs, pred_lens, true_seqs_lens,
                                             boost_targets=boost_targets, enforce_minimum=enforce_minimum)
         res.raise_for_status()
-        return res.to_lists()
+        out = res.to_lists()
+        return out if lazy else out.tolist()
 
-    def decode_alignments_simple(self, log_probs, true_seqs, pred_lens=None, true_seqs_lens=None):
+    def decode_alignments_simple(self, log_probs, true_seqs, pred_lens=None, true_seqs_lens=None, lazy=False):
         """forced_alignment.py:932-987 (no boost / floor / anchoring; float32 band arithmetic)."""
         B, Tmax = log_probs.shape[0], log_probs.shape[1]
         if pred_lens is None:
@@ -586,7 +617,8 @@ class AlignmentUtils:
         res = self.viterbi_decoder.align_batch(log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=False,
                                                enforce_minimum=False, anchor_pauses=False, simple=True)
         res.raise_for_status()
-        return res.to_lists()
+        out = res.to_lists()
+        return out if lazy else out.tolist()
 
 
 def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,
@@ -644,6 +676,6 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
     for c in calls:
         res = ViterbiDecoder._result(c)
         res.conf, res.conf_status = c.get("conf"), c.get("cstat")
-        res.postprocessed = post is not None  # coverage / soft boundaries already ran in place (they are not idempotent)
+        res.postprocessed = post is not None
         out.append((res, c["stats"]))
     return out

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BFA_ABI_VERSION 4 /* v4: bfa_set_option; v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
+#define BFA_ABI_VERSION 5 /* v5: bfa_pack_results / bfa_pack_words / bfa_index_records (packed result records); v4: bfa_set_option; v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
 
 typedef struct bfa_context *bfa_handle;
 
@@ -85,14 +85,31 @@ typedef struct {
     int32_t max_blanks;      /* assort_frames(max_blanks=10) */
     /* ---- optional host hints (ABI v2 names; v1 carried them as reserved[0..2]).  0 = library default. ---- */
     int32_t class_mask;        /* which K1 kernel classes are worth launching (0 = derive everything from the tensor
-                                  shapes): bits 0-6  full-layout states-per-lane classes {2,3,4,6,8,12,16},
-                                  bits 8-15 sliding-window classes Rw in {1,2,3,4,6,8} (bit 7+Rw),
-                                  bit 16    BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
-                                            silence-anchored planning kernels are not launched.
-                                  bit 17    BFA_HINT_UNIFORM_LENGTHS: the utterances of this call have about the same
-                                            number of frames (a speed hint only: each XCD then takes one contiguous
-                                            eighth of the batch; with very different lengths ordered by length it
-                                            would load the XCDs unevenly -- results are the same either way).
+                                  shapes):
+                                  bits 0-6   full-layout states-per-lane classes {2,3,4,6,8,12,16};
+                                  bits 8-15  sliding-window ("fast window") classes Rw in {1,2,3,4,6,8} at bit 7+Rw: in-band
+                                             states only; the result stands while the path score stays above the -1000
+                                             sentinel, otherwise the utterance is redone (no hint bit needed for that);
+                                  bit 16     BFA_HINT_NO_SILENCE_TARGETS: no target contains silence_id, so the
+                                             silence-anchored planning kernels are not launched;
+                                  bit 17     BFA_HINT_UNIFORM_LENGTHS: the utterances of this call have about the same
+                                             number of frames.  Results are the same either way, but it SELECTS KERNELS:
+                                             with it, each class runs as its own kernel and each XCD takes one contiguous
+                                             eighth of the batch (right for the headline batch: 0.33 + 0.06 ms); without it a
+                                             call of two utterances or more on the head widths (C = 67 / 17, default flags,
+                                             no silence anchoring) is taken as a MIXED-LENGTH call: one kernel aligns and walks
+                                             every utterance, longest first (right for T ~ U[200, 3000]: 1.1 against 1.6 ms per
+                                             4096 utterances, but 1.2 against 0.4 ms on a uniform batch).  A caller whose
+                                             lengths live on the device and are known to be uniform should set it; T_len ==
+                                             NULL (every utterance has Tmax frames) sets it implicitly;
+                                  bits 20-27 exact-window classes Rw in {1,2,3,4,6,8} at bit 19+Rw: in-band states computed
+                                             exactly in every regime (utterances with more frames / tokens than the fast
+                                             window is tried on, stride >= 3; in a mixed-length call every stride >= 3
+                                             window item of the classes Rw <= 4 -- there a fast-window bit stands for its
+                                             exact twin).
+                                  "Hinted" = any of bits 0-15 / 20-27 set.  A small call (B <= 1024, 4 * Smax + 1 <= 256) whose
+                                  hint names exactly ONE fast-window class Rw <= 3 and nothing else runs as one kernel per
+                                  utterance (plan + DP + rerun + walk).  bfa_call_path reports which layout a call takes.
                                   A hint that excludes what an utterance needs is reported as BFA_ITEM_BAD_HINT. */
     int32_t window_max_tokens; /* 0 = 64.  K1's sliding-window variant is exact only while the path score stays above
                                   the reference's -1000 sentinel; otherwise the utterance is redone with the full state
@@ -129,6 +146,14 @@ void bfa_params_default(bfa_params *p, int blank_id, int silence_id);
 /* bytes of device scratch bfa_align_batch needs for these shapes (shape-only upper bound, so no
  * host knowledge of the per-utterance lengths is required) */
 size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p);
+
+/* Which launch layout bfa_align_batch takes for these shapes and hints (host arithmetic only, no device needed):
+ * 0 = one kernel per class side by side, 1 = the one-kernel mixed-length path (plus class kernels for the wide classes),
+ * 2 = the one-kernel path of small single-class calls.  has_T_len = 0 means T_len == NULL. */
+#define BFA_PATH_CLASS_KERNELS 0
+#define BFA_PATH_MIXED 1
+#define BFA_PATH_ONE_KERNEL 2
+int bfa_call_path(int B, int Tmax, int Smax, int C, const bfa_params *p, int has_T_len);
 
 /*
  * AlignmentUtils.decode_alignments / decode_alignments_simple for a whole batch.
@@ -247,6 +272,12 @@ int bfa_profile_collect(bfa_handle h, float *out_ms_host, int cap);
  * handles is the time the kernel was running at all, which is what a throughput figure has to be priced against.
  */
 int bfa_profile_collect_spans(bfa_handle h, void *base_event, float *out_start_ms_host, float *out_end_ms_host, int cap);
+/*
+ * The copy ceiling of this GPU, for pricing the roofline against what the memory system delivers rather than the 8 TB/s of
+ * the data sheet: one launch of a float4 copy kernel dst[i] = src[i] over `bytes` (a multiple of
+ * 16; 2 x bytes of HBM traffic) on `stream`.  The caller times it (events on that stream).
+ */
+int bfa_profile_copy(bfa_handle h, void *dst, const void *src, size_t bytes, void *stream);
 
 /*
  * Window stitching, the step in front of the path: stich_window_predictions
@@ -261,6 +292,34 @@ int bfa_stitch_windows(bfa_handle h, const float *window_logits, int B, int NW, 
 /* F.log_softmax(dim=-1) of raw logits [rows,C] (core.py:898-899), torch-CPU-exact numerics */
 int bfa_log_softmax(bfa_handle h, const float *logits, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
                     int C, void *stream);
+
+/*
+ * Packed result records (ABI v5).  The tuples of a call sit in a padded [n, seg_cap] array; what LEAVES the GPU -- the copy
+ * to the host behind AlignmentUtils.decode_alignments' list of lists (forced_alignment.py:871,908), the final gather of a
+ * batch sharded over several GPUs ("one collective at the end ... of per-utterance result records")
+ * -- needs the valid tuples only.  bfa_pack_results writes them back to back (CSR) into ONE caller-owned int32 buffer `out`
+ * of bfa_pack_words(n_cap, tuple_cap, conf != NULL) words, in one kernel launch and without host knowledge of the counts:
+ *
+ *   word 0 n | 1 total tuples (<= tuple_cap) | 2 n_cap | 3 tuple_cap | 4 has_conf | 5 overflow (tuples cut at tuple_cap) | 6-7 zero
+ *   gidx  [n_cap]  global index of utterance j: global_index[j], or gidx_base + j when global_index is NULL; -1 for j >= n
+ *   count [n_cap]  tuples of utterance j (min(seg_count[j], seg_cap))
+ *   offset[n_cap]  exclusive prefix sum of count
+ *   tuples[tuple_cap] bfa_segment (16-byte aligned), utterance after utterance
+ *   conf  [tuple_cap] float32, only when conf != NULL
+ * (each of the three [n_cap] tables starts at a multiple of four words.)  n_cap >= n and tuple_cap are the CALLER's bounds:
+ * ranks that exchange records of equal size agree on them from shapes they all know (the largest shard, the largest sum of
+ * target lengths), so the exchange needs no size round trip.
+ */
+int64_t bfa_pack_words(int n_cap, int64_t tuple_cap, int has_conf);
+int bfa_pack_results(bfa_handle h, const bfa_segment *segs, int seg_cap, const int32_t *seg_count, const float *conf,
+                     const int32_t *global_index, int gidx_base, int n, int n_cap, int tuple_cap, int32_t *out, void *stream);
+/*
+ * The receiving side: `records` = world records of `words` int32 each, as bfa_pack_results wrote them (one per rank, e.g. the
+ * output of a gather).  For every global utterance index g < n_total named by a record: owner[g] = which record,
+ * offset[g] = its first tuple inside that record's tuple section, count[g].  Entries no record names are left untouched.
+ */
+int bfa_index_records(bfa_handle h, const int32_t *records, int world, int64_t words, int n_max, int n_total,
+                      int32_t *out_owner, int32_t *out_offset, int32_t *out_count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= set(names)
     lib.bfa_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.bfa_version()
-    assert lib.bfa_abi_version() == 4
+    assert lib.bfa_abi_version() == 5
 
 
 def test_params_default_and_workspace_query():
@@ -170,15 +170,19 @@ def _gloo_worker(rank, world, port, tmp):
     out = gather_results(torch.from_numpy(segs[mine][:, :local_cap]), torch.from_numpy(np.minimum(cnt[mine], local_cap)),
                          torch.from_numpy(conf[mine][:, :local_cap]), torch.from_numpy(mine), n, dst=0)
     if rank == 0:
-        gs, gc, gf = out
-        ok = True
+        gs, gc, gf = out.to_padded(cap)   # the padded arrays one call would have returned, original order
+        ok = not out.overflowed() and out.records.shape[0] == world
+        lists = out.to_lists()
         for i in range(n):
             r = next(k for k in range(world) if i in shards[k])
             lc = int(S[shards[r]].max()) + 2
             c = min(int(cnt[i]), lc)
             ok &= int(gc[i]) == c
-            ok &= bool((gs[i, :c].numpy() == segs[i, :c]).all())
+            ok &= bool((gs[i, :c].numpy() == segs[i, :c]).all()) and bool((gs[i, c:] == 0).all())
             ok &= bool((gf[i, :c].numpy() == conf[i, :c]).all())
+            t, cf = out.rows(i)             # straight from the packed records
+            ok &= t.shape == (c, 4) and bool((t == segs[i, :c]).all()) and bool((cf == conf[i, :c]).all())
+            ok &= lists[i] == [tuple(x) for x in segs[i, :c].tolist()]
         open(os.path.join(tmp, "ok"), "w").write("1" if ok else "0")
     else:
         assert out is None
@@ -512,11 +516,15 @@ def _gloo_worker8(rank, world, port, tmp):
     out = gather_results(torch.from_numpy(segs[mine][:, :cap]), torch.from_numpy(cnt[mine]), torch.from_numpy(conf[mine][:, :cap]),
                          torch.from_numpy(mine.astype(np.int64)), n, dst=0)
     if rank == 0:
-        gs, gc, gf = out
-        ok = gs.shape == (n, capmax, 4)
+        gs, gc, gf = out.to_padded(capmax)
+        ok = gs.shape == (n, capmax, 4) and not out.overflowed()
+        # the payload is the packed tuples, not n x capmax padded rows: 8 ranks x (header + tables + 20 B per tuple of the fullest bound)
+        ok &= out.records.numel() * 4 <= 8 * (32 + 3 * 4 * 8 + 20 * 7 * capmax + 64)
         for i in range(n):
             c = int(cnt[i])
             ok &= int(gc[i]) == c and bool((gs[i, :c].numpy() == segs[i, :c]).all()) and bool((gf[i, :c].numpy() == conf[i, :c]).all())
+            t, cf = out.rows(i)
+            ok &= bool((t == segs[i, :c]).all()) and bool((cf == conf[i, :c]).all())
         open(os.path.join(tmp, "ok8"), "w").write("1" if ok else "0")
     else:
         assert out is None
@@ -568,3 +576,55 @@ def test_lazy_row_lists_behave_like_the_reference_list_of_lists():
     with pytest.raises(IndexError):
         lazy[40]
     assert LazyRowLists(rec[:0], []) == [] and len(LazyRowLists(rec[:0], [0, 0])) == 2
+
+
+def test_hint_and_launcher_agree_on_the_launch_layout():
+    """ViterbiDecoder.hint_and_path (the host-side hint and the layout it is written for) against bfa_call_path (the
+    library's own decision from the same shapes and hint; host arithmetic, no device): per-class kernels, the one-kernel
+    mixed-length path, the one-kernel path of small single-class calls.  The constants on both sides are the same ones."""
+    import ctypes
+    from bournemouth_forced_aligner_amd import _lib
+    from bournemouth_forced_aligner_amd.forced_alignment import ViterbiDecoder
+    L = _lib.lib()
+    src = open(os.path.join(ROOT, "bournemouth-forced-aligner_amd", "csrc", "bfa_types.hpp")).read()
+    assert f"ONE_MAX_BATCH = {_lib.ONE_MAX_BATCH};" in src and f"#define BFA_MIX_MIN_BATCH {_lib.MIX_MIN_BATCH}\n" in src
+    assert _lib.ONE_HINT_MAX_BATCH <= _lib.ONE_MAX_BATCH
+    rng = np.random.default_rng(17)
+    seen = set()
+    for trial in range(400):
+        C = int(rng.choice([67, 17, 40]))
+        vd = ViterbiDecoder(C - 1, 0, silence_anchors=10, truly_forced=True)
+        B = int(rng.choice([1, 2, 3, 16, 63, 64, 65, 300, 1024, 1025, 4096]))
+        kind = rng.integers(0, 5)
+        if kind == 0:      # uniform lengths (the headline shape and smaller ones)
+            T = np.full(B, int(rng.choice([200, 600, 1000, 2000])))
+            S = np.full(B, int(rng.choice([5, 20, 40, 63, 64, 70])))
+        elif kind == 1:    # mixed lengths, S = T // 25 (C4)
+            T = rng.integers(200, 3001, size=B)
+            S = np.maximum(1, T // 25)
+        elif kind == 2:    # short sentences of one class
+            T = rng.integers(300, 420, size=B)
+            S = np.full(B, int(rng.choice([16, 20, 30])))
+        elif kind == 3:    # dense targets (strides below 4, proportional, too short) and empty ones
+            T = rng.integers(20, 400, size=B)
+            S = np.minimum(rng.integers(0, 120, size=B), T + 3)
+        else:              # long paths (wide classes)
+            T = rng.integers(1500, 3000, size=B)
+            S = rng.integers(100, 400, size=B)
+        has_sil = bool(rng.integers(0, 4) == 0)
+        simple = bool(rng.integers(0, 8) == 0)
+        pad = int(rng.choice([0, 0, 0, 7, 40]))
+        Smax = max(1, int(S.max()) + pad)
+        mask, path = vd.hint_and_path(T, S, has_sil, simple=simple, n_classes=C, Smax=Smax)
+        p = vd._params(True, True, not simple, simple)
+        p.class_mask = int(mask)
+        got = L.bfa_call_path(B, int(T.max()), Smax, C, ctypes.byref(p), 1)
+        assert got == path, (trial, C, B, kind, has_sil, simple, pad, hex(mask), got, path)
+        seen.add(got)
+    assert seen == {_lib.PATH_CLASS_KERNELS, _lib.PATH_MIXED, _lib.PATH_ONE_KERNEL}
+    # T_len == NULL: every utterance has Tmax frames -> never the mixed-length path, with or without a hint
+    vd = ViterbiDecoder(66, 0, silence_anchors=10, truly_forced=True)
+    p = vd._params(True, True, True)
+    p.class_mask = _lib.HINT_NO_SILENCE_TARGETS
+    assert L.bfa_call_path(4096, 1000, 40, 67, ctypes.byref(p), 1) == _lib.PATH_MIXED
+    assert L.bfa_call_path(4096, 1000, 40, 67, ctypes.byref(p), 0) == _lib.PATH_CLASS_KERNELS

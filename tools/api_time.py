@@ -39,8 +39,10 @@ lists_ms, _ = timed(lambda: res.to_lists())                       # the lazy lis
 touch1_ms, _ = timed(lambda: res.to_lists()[17])                  # ... and one utterance's tuples
 all_ms, _ = timed(lambda: res.to_lists().tolist())                # ... and every tuple (one numpy pass)
 iter_ms, _ = timed(lambda: sum(len(r) for r in res.to_lists()))   # ... every tuple through iteration
-full_ms, rows = timed(lambda: au.decode_alignments(lp, toks, Tl, Sl))
+full_ms, rows = timed(lambda: au.decode_alignments(lp, toks, Tl, Sl))              # the reference's return type: list of lists of tuples
+lazy_ms, _ = timed(lambda: au.decode_alignments(lp, toks, Tl, Sl, lazy=True))       # LazyRowLists (opt-in)
+assert type(rows) is list and type(rows[0]) is list and type(rows[0][0]) is tuple
 print(json.dumps({"workload": f"batch={B} T={T} S={S} ph66, device-resident inputs", "decode_alignments_device_ms": dev_ms,
                   "to_lists_ms": lists_ms, "to_lists_one_utterance_ms": touch1_ms, "to_lists_every_tuple_ms": all_ms,
-                  "to_lists_iterate_ms": iter_ms, "decode_alignments_ms": full_ms, "tuples": sum(len(r) for r in rows),
+                  "to_lists_iterate_ms": iter_ms, "decode_alignments_ms": full_ms, "decode_alignments_lazy_ms": lazy_ms, "tuples": sum(len(r) for r in rows),
                   "frames_per_s_through_decode_alignments": B * T / (full_ms * 1e-3)}))
