@@ -23,6 +23,23 @@ _ROW8 = np.dtype([("id", "<i4"), ("start", "<i4"), ("end", "<i4"), ("idx", "<i4"
                   ("start_ms", "<f4"), ("end_ms", "<f4")])
 
 
+def _to_host(*tensors):
+    """device tensors -> numpy arrays through pinned memory: the copies are enqueued back to back, ONE synchronisation"""
+    outs = []
+    dev = None
+    for t in tensors:
+        if t.is_cuda:
+            dev = t.device
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            outs.append(h)
+        else:
+            outs.append(t)
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+    return [h.numpy() for h in outs]
+
+
 def _pad_rows(rows, fill):
     """list of id lists -> int32 [B, max(1, longest)] tensor padded with `fill` (core.py:848-853)."""
     lens = np.fromiter((len(r) for r in rows), np.int64, len(rows))
@@ -271,11 +288,17 @@ class PhonemeTimestampAligner:
             heads.append(("group_timestamps", self.alignment_utils_g, lp_g, gr))  # always runs (core.py:914)
             pending = [(key, self._head(utils, lp, seqs, ph_seq_lens, spec)) for key, utils, lp, seqs in heads]
         arrays = {}
-        for key, (res, conf, cstat, estimated) in pending:
-            res.raise_for_status()
-            if int((cstat.cpu() != 0).sum()) != 0:
+        # every head's results in ONE round of copies (pinned, one synchronisation) instead of five blocking ones per head
+        flat = _to_host(*[t for _, (res, conf, cstat, _e) in pending for t in (res.status, cstat, res.seg_count, res.segs, conf)])
+        for k, (key, (res, conf, cstat, estimated)) in enumerate(pending):
+            st_h, cs_h = flat[5 * k], flat[5 * k + 1]
+            if (st_h != 0).any():
+                res.raise_for_status()
+            if (cs_h != 0).any():
                 raise IndexError("confidence pass: phoneme id or start frame out of range")
+            res._host3 = flat[5 * k + 2:5 * k + 5]
             arrays[key] = self._shape_rows(res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays)
+            res._host3 = None
         # (the reference returns a list of B dicts of lists of 8-tuples: here that list builds an utterance's dict and tuples
         # when it is looked at -- 327 680 tuples of the headline batch cost CPython ~85 ms whoever builds them)
         if as_arrays:
@@ -289,9 +312,7 @@ class PhonemeTimestampAligner:
         reference's 8-tuples -- or, with `as_arrays`, as padded numpy arrays (no per-row Python objects: on a
         4096-utterance batch building the tuples costs far more than the device passes)."""
         f32 = np.float32
-        cnt = res.seg_count.cpu().numpy()
-        segs = res.segs.cpu().numpy()
-        cf = conf.cpu().numpy()
+        cnt, segs, cf = res._host3 if getattr(res, "_host3", None) is not None else _to_host(res.seg_count, res.segs, conf)
         B, cap = segs.shape[0], segs.shape[1]
         sl = np.asarray(spec, np.int64)
         dur = (np.asarray(wav_lens, np.float64) / float(self.resampler_sample_rate)).astype(f32)
@@ -299,21 +320,26 @@ class PhonemeTimestampAligner:
             dpf = np.where(sl > 0, (f32(1) / sl.astype(f32)) * dur, f32(0)).astype(f32)
         per_item = isinstance(start_offset_times, (list, tuple))
         off = np.asarray(start_offset_times if per_item else [start_offset_times] * B, np.float64).astype(f32)
-        sms = ((off[:, None] + segs[:, :, 1].astype(f32) * dpf[:, None]) * f32(1000)).astype(f32)
-        ems = ((off[:, None] + segs[:, :, 2].astype(f32) * dpf[:, None]) * f32(1000)).astype(f32)
+        # start and end frames in one pass: (offset + frame * seconds_per_frame) * 1000, each operation rounded to float32
+        ms = segs[:, :, 1:3].astype(f32)
+        ms *= dpf[:, None, None]
+        ms += off[:, None, None]
+        ms *= f32(1000)
+        sms, ems = ms[:, :, 0], ms[:, :, 1]
         est = np.zeros((B, cap), bool)
         if estimated:
             for b, flags in enumerate(estimated):
                 est[b, :len(flags)] = flags
-        valid = np.arange(cap)[None, :] < cnt[:, None]
-        # core.py:955-956 sorts by start_ms; the rows come sorted by start frame, so this only ever reorders
-        # when two start frames round to out-of-order float32 times (never seen; handled for exactness)
-        bad = ((np.diff(sms, axis=1) < 0) & valid[:, 1:]).any(axis=1)
-        for b in np.nonzero(bad)[0]:
-            n = int(cnt[b])
-            order = np.argsort(sms[b, :n], kind="stable")
-            for a in (segs, cf, sms, ems, est):
-                a[b, :n] = a[b, :n][order]
+        # core.py:955-956 sorts by start_ms (stable).  Rounding is monotonic, so rows sorted by start FRAME are sorted by
+        # start_ms too and the sort is the identity; only utterances whose start frames are out of order need it
+        starts = segs[:, :, 1]
+        bad = np.flatnonzero((starts[:, 1:] < starts[:, :-1]).any(axis=1))
+        for b in bad:
+            n = int(min(cnt[b], cap))
+            if (np.diff(sms[b, :n]) < 0).any():
+                order = np.argsort(sms[b, :n], kind="stable")
+                for a in (segs, cf, sms, ems, est):
+                    a[b, :n] = a[b, :n][order]
         if as_arrays:
             return {"rows": segs, "count": cnt, "is_estimated": est, "confidence": cf[:, :cap], "start_ms": sms,
                     "end_ms": ems}

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void k_conf(ConfArgs a)
         if (T > a.Tmax) T = a.Tmax;
         int n = a.seg_count[b];
         if (n > a.seg_cap) n = a.seg_cap;
+        for (int i = (n < 0 ? 0 : n) + lane; i < a.seg_cap; i += 64) cf[i] = 0.0f; // the caller's buffer needs no fill ahead of the call
         int bad = 0;
         // ---- does any tuple read a cell that an earlier tuple has written through its 0-dim view?
         int alias = 0;

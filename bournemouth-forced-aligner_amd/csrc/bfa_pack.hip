@@ -127,16 +127,13 @@ __global__ __launch_bounds__(256) void k_index_records(const int32_t *__restrict
     }
 }
 
-// The copy ceiling (bfa_profile_copy): float4 copy, grid-stride, four loads in flight per thread.
+// The copy ceiling (bfa_profile_copy): float4 copy, grid-stride, 1024 workgroups (four per CU) -- the fastest of the
+// variants of tools/ubench/copy_peak.hip on this part (6.0 TB/s over 1 GiB, 5.6 over 3 GiB; unrolled, chunked and
+// non-temporal forms and hipMemcpyAsync reach 4.4-5.9).
 __global__ __launch_bounds__(256) void k_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
 } // namespace bfa
@@ -144,7 +141,7 @@ __global__ __launch_bounds__(256) void k_copy(float4 *__restrict__ dst, const fl
 extern "C" int bfa_launch_copy(void *dst, const void *src, size_t bytes, void *stream)
 {
     const size_t n = bytes / 16;
-    hipLaunchKernelGGL(bfa::k_copy, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n);
+    hipLaunchKernelGGL(bfa::k_copy, dim3(1024), dim3(256), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n);
     return (int)hipGetLastError();
 }
 

@@ -227,12 +227,26 @@ class AlignmentResult:
         76 ms on the 4096-utterance headline batch against 0.35 ms of device time)."""
         from .sharding import pack_layout, pack_results
         n, cap = int(self.segs.shape[0]), int(self.segs.shape[1])
-        rec = pack_results(self.segs, self.seg_count, None, None, n, n * cap)
-        lay = pack_layout(n, n * cap, False)
-        head = rec[:lay["tuples"]].cpu().numpy()
-        total = int(head[1])
+        bound = n * cap
+        rec = pack_results(self.segs, self.seg_count, None, None, n, bound)
+        lay = pack_layout(n, bound, False)
+        st = torch.cuda.current_stream(rec.device)
+        if lay["words"] * 4 <= (8 << 20):   # one copy of the whole record into pinned memory, one synchronisation
+            host = torch.empty((lay["words"],), dtype=torch.int32, pin_memory=True)
+            host.copy_(rec, non_blocking=True)
+            st.synchronize()
+            head = host.numpy()
+            total = int(head[1])
+            packed = head[lay["tuples"]:lay["tuples"] + 4 * total]
+        else:                               # the count table first, then exactly the packed tuples
+            head = rec[:lay["tuples"]].cpu().numpy()
+            total = int(head[1])
+            host = torch.empty((4 * total,), dtype=torch.int32, pin_memory=True)
+            host.copy_(rec[lay["tuples"]:lay["tuples"] + 4 * total], non_blocking=True)
+            st.synchronize()
+            packed = host.numpy()
         cnt = head[lay["count"]:lay["count"] + n]
-        packed = rec[lay["tuples"]:lay["tuples"] + 4 * total].cpu().numpy()
+        self._host_record = host  # (the numpy views above live in this pinned block)
         return LazyRowLists(packed.view(_ROW4).reshape(-1), cnt)
 
 
@@ -254,6 +268,9 @@ class ViterbiDecoder:
         self.window_max_tokens = None
         self.window_max_frames = None   # likewise for the frame limit (bfa_params.window_max_frames)
         self.handle_slot = 0            # which of the process's handles this decoder uses (see _lib.handle)
+        self._hint_cache = {}           # hint_and_path results by length vector
+        self._dev_hint = {}             # ... and for lengths / targets that live on the device, by tensor identity
+        self.hint_from_device_lengths = True  # see _hint_of_device_lengths
 
     def set_blank_id(self, blank_id):
         """forced_alignment.py:25-27"""
@@ -318,6 +335,27 @@ class ViterbiDecoder:
 
     def hint_and_path(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
                       boost_targets=True, enforce_minimum=True, Smax=None):
+        """Cached front of _hint_and_path: the hint of a batch depends on its (T, S) pairs only, and callers align batch
+        after batch of the same shape -- the numpy passes over 4096 lengths cost 0.3 ms per call, as much as the device
+        step.  All-equal lengths are reduced to one pair; other length vectors are looked up by their bytes."""
+        T = np.ascontiguousarray(np.asarray(list(T_lens) if not isinstance(T_lens, np.ndarray) else T_lens, dtype=np.int64).reshape(-1))
+        S = np.ascontiguousarray(np.asarray(list(S_lens) if not isinstance(S_lens, np.ndarray) else S_lens, dtype=np.int64).reshape(-1))
+        if T.size and T.size == S.size and int(T.min()) == int(T.max()) and int(S.min()) == int(S.max()):
+            lens_key = ("eq", T.size, int(T[0]), int(S[0]))
+        else:
+            lens_key = (T.tobytes(), S.tobytes())
+        key = (lens_key, bool(has_sil), bool(anchor_pauses), bool(simple), n_classes, bool(boost_targets), bool(enforce_minimum), Smax,
+               self.silence_anchors, self.silence_id, self.min_phoneme_prob, self.window_max_tokens, self.window_max_frames)
+        hit = self._hint_cache.get(key)
+        if hit is None:
+            hit = self._hint_and_path(T, S, has_sil, anchor_pauses, simple, n_classes, boost_targets, enforce_minimum, Smax)
+            if len(self._hint_cache) >= 16:
+                self._hint_cache.pop(next(iter(self._hint_cache)))
+            self._hint_cache[key] = hit
+        return hit
+
+    def _hint_and_path(self, T_lens, S_lens, has_sil, anchor_pauses=True, simple=False, n_classes=None,
+                       boost_targets=True, enforce_minimum=True, Smax=None):
         """(class_mask, path): the hint and the launch layout it is written for (_lib.PATH_*; the library's own decision
         for the same shapes is bfa_call_path -- tests/test_host_and_abi.py holds the two against each other).  `Smax`: the
         padded target width the call will pass (default: the longest target).
@@ -410,6 +448,31 @@ class ViterbiDecoder:
             path = _lib.PATH_CLASS_KERNELS if (seg or not window_ok or Lmax_call <= 60 or T.size < _lib.MIX_MIN_BATCH) else _lib.PATH_MIXED
         return mask, path
 
+    def _hint_of_device_lengths(self, pred_lens, true_seqs_lens, true_seqs, B, Tmax, toks, sil, hint_kw):
+        """The class hint for lengths / targets that live on the DEVICE: without it the library has to assume silence
+        anchoring and every class (0.75 against 0.40 ms on the headline batch).  The first call with a given set of
+        tensors reads them once (one small copy to the host, i.e. one synchronisation); the hint is then kept by tensor
+        IDENTITY and version counter, so a caller that aligns the same lengths again -- or batch after batch through the
+        same length tensors without writing to them -- pays nothing.  `hint_from_device_lengths = False` switches this
+        off (the call then never touches the host)."""
+        import weakref
+        ts = [t for t in (pred_lens, true_seqs_lens, true_seqs) if isinstance(t, torch.Tensor)]
+        key = tuple((id(t), t._version, t.data_ptr()) for t in ts) + tuple(sorted(hint_kw.items())) + (B, Tmax, sil)
+        hit = self._dev_hint.get(key)
+        if hit is not None and all(r() is t for r, t in zip(hit[1], ts)):
+            return hit[0]
+        Th = np.full(B, Tmax, np.int64) if pred_lens is None else _host_ints(pred_lens.cpu() if isinstance(pred_lens, torch.Tensor) else pred_lens)
+        Sh = _host_ints(true_seqs_lens.cpu())
+        if len(Th) != B or len(Sh) != B:
+            return 0
+        valid = torch.arange(toks.shape[1], device=toks.device)[None, :] < true_seqs_lens.to(toks.device)[:, None]
+        has_sil = bool(((toks == sil) & valid).any())
+        mask = self.hint_and_path(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil, **hint_kw)[0]
+        if len(self._dev_hint) >= 8:
+            self._dev_hint.pop(next(iter(self._dev_hint)))
+        self._dev_hint[key] = (mask, [weakref.ref(t) for t in ts])
+        return mask
+
     @staticmethod
     def _uniform(T):
         return T.size >= 64 and int(T.max() - T.min()) * 8 <= int(T.max())
@@ -437,14 +500,17 @@ class ViterbiDecoder:
             # lengths (and tokens) that are still on the host cost nothing to look at: derive the class hint, so
             # that only the K1 classes of this batch are launched (class_mask=None keeps the library's own choice)
             Th, Sh = _host_ints(pred_lens), _host_ints(true_seqs_lens)
+            if Th is None and pred_lens is None:
+                Th = np.full(B, Tmax, np.int64)
+            sil = self.silence_id if self.silence_id is not None else -1
+            hint_kw = dict(anchor_pauses=anchor_pauses, simple=simple, n_classes=C, boost_targets=boost_targets,
+                           enforce_minimum=enforce_minimum, Smax=Smax)
             if Th is not None and Sh is not None and len(Th) == B and len(Sh) == B:
                 tk_host = _host_array(true_seqs)
-                sil = self.silence_id if self.silence_id is not None else -1
                 has_sil = True if tk_host is None else bool((tk_host == sil).any())
-                class_mask = self.hint_and_path(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil,
-                                                anchor_pauses=anchor_pauses, simple=simple, n_classes=C,
-                                                boost_targets=boost_targets, enforce_minimum=enforce_minimum,
-                                                Smax=Smax)[0]
+                class_mask = self.hint_and_path(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil, **hint_kw)[0]
+            elif self.hint_from_device_lengths and isinstance(true_seqs_lens, torch.Tensor):
+                class_mask = self._hint_of_device_lengths(pred_lens, true_seqs_lens, true_seqs, B, Tmax, toks, sil, hint_kw)
         S_len = _as_i32(true_seqs_lens, dev)
         T_len = _as_i32(pred_lens, dev)
         params = self._params(boost_targets, enforce_minimum, anchor_pauses, simple, max_blanks)
@@ -660,8 +726,8 @@ def align_heads(utils_list, logits_list, seqs_list, pred_lens, true_seqs_lens, b
             hd.postprocess, hd.extend = 1, int(bool(post.get("extend", True)))
             hd.boundary_softness = int(post.get("boundary_softness", 3))
             if post.get("confidences", True):
-                c["conf"] = torch.zeros((c["B"], c["seg_cap"]), dtype=torch.float32, device=c["dev"])
-                c["cstat"] = torch.zeros((c["B"],), dtype=torch.int32, device=c["dev"])
+                c["conf"] = torch.empty((c["B"], c["seg_cap"]), dtype=torch.float32, device=c["dev"])  # (written in full by the kernel)
+                c["cstat"] = torch.empty((c["B"],), dtype=torch.int32, device=c["dev"])
                 hd.out_conf, hd.out_conf_status = c["conf"].data_ptr(), c["cstat"].data_ptr()
     dev = c0["dev"]
     L = _lib.lib()

@@ -27,8 +27,8 @@ def calculate_confidences_batch(log_probs, segs, seg_count, T_rows=None, row_sta
     seg_count = _as_i32(seg_count, dev)
     T_rows = _as_i32(T_rows, dev)
     seg_cap = segs.shape[1]
-    conf = torch.zeros((B, seg_cap), dtype=torch.float32, device=dev)
-    status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    conf = torch.empty((B, seg_cap), dtype=torch.float32, device=dev)   # (the kernel writes every entry: zeros beyond the count)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
     L = _lib.lib()
     h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device(), handle_slot)
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -28,18 +28,20 @@ al = PhonemeTimestampAligner(device="cuda:0", phoneme_id_to_group_id=gmap)
 seqs = toks.cpu().tolist()
 spec = [T] * B
 wl = [T * 268] * B
-for as_arrays in ((True,) if len(sys.argv) > 2 else (False, "lazy", True)):
+for as_arrays in ((True,) if len(sys.argv) > 2 else (False, "lazy", True, "tensor")):
     for it in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        kw = {"as_arrays": True} if as_arrays is True else ({"lazy": True} if as_arrays == "lazy" else {})
-        out = al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, fused=FUSED, **kw)
+        kw = {"as_arrays": True} if as_arrays in (True, "tensor") else ({"lazy": True} if as_arrays == "lazy" else {})
+        # "tensor": the targets as the padded int tensor the reference builds at core.py:848-853 instead of lists of ids
+        out = al.extract_timestamps_from_logits(lp, lg, spec, toks if as_arrays == "tensor" else seqs, wl,
+                                                start_offset_times=0.0, fused=FUSED, **kw)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     print(f"B={B} fused={FUSED} as_arrays={as_arrays}: {dt * 1e3:.1f} ms per call ({B * T / dt / 1e6:.1f} M frames/s through the API)")
     import json
     print(json.dumps({"workload": f"PhonemeTimestampAligner.extract_timestamps_from_logits, batch={B} T={T} S={S}, both heads from raw "
-                                  f"logits, fused={FUSED}", "result": "padded arrays" if as_arrays is True else ("lazy list of dicts (lazy=True)" if as_arrays == "lazy" else "the reference's list of dicts of lists of 8-tuples"),
+                                  f"logits, fused={FUSED}", "result": "padded arrays" if as_arrays is True else "padded arrays, targets given as a padded tensor" if as_arrays == "tensor" else ("lazy list of dicts (lazy=True)" if as_arrays == "lazy" else "the reference's list of dicts of lists of 8-tuples"),
                       "ms_per_call_host_and_device": dt * 1e3, "frames_per_s_through_the_api": B * T / dt}))
     if hasattr(al, "last_device_ms"):
         print("   device passes:", {k: round(v, 3) for k, v in al.last_device_ms.items()})
