@@ -24,20 +24,10 @@ _ROW8 = np.dtype([("id", "<i4"), ("start", "<i4"), ("end", "<i4"), ("idx", "<i4"
 
 
 def _to_host(*tensors):
-    """device tensors -> numpy arrays through pinned memory: the copies are enqueued back to back, ONE synchronisation"""
-    outs = []
-    dev = None
-    for t in tensors:
-        if t.is_cuda:
-            dev = t.device
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            h.copy_(t, non_blocking=True)
-            outs.append(h)
-        else:
-            outs.append(t)
-    if dev is not None:
-        torch.cuda.current_stream(dev).synchronize()
-    return [h.numpy() for h in outs]
+    """device tensors -> numpy arrays, one after the other (the first copy waits for the device, the rest are plain copies;
+    pinned staging per call was measured and lost: 27.8 against 6.9 ms per headline call, the pinned blocks of results the
+    caller still holds cannot be recycled)"""
+    return [t.cpu().numpy() for t in tensors]
 
 
 def _pad_rows(rows, fill):
@@ -269,7 +259,7 @@ class PhonemeTimestampAligner:
         else:
             gr = group_sequences.to(torch.int32)
         spec = [int(x) for x in spectral_lens]
-        if fused and logits_class.shape[-1] >= 16 and logits_group.shape[-1] >= 16:
+        if fused:
             # raw logits of both heads in, log_softmax (core.py:898-899) inside the alignment
             # kernels, both heads from one bfa_align_heads call; the later stages read (logits, row statistics)
             xs = [logits_class.to(device=dev, dtype=torch.float32), logits_group.to(device=dev, dtype=torch.float32)]
@@ -333,7 +323,8 @@ class PhonemeTimestampAligner:
         # core.py:955-956 sorts by start_ms (stable).  Rounding is monotonic, so rows sorted by start FRAME are sorted by
         # start_ms too and the sort is the identity; only utterances whose start frames are out of order need it
         starts = segs[:, :, 1]
-        bad = np.flatnonzero((starts[:, 1:] < starts[:, :-1]).any(axis=1))
+        live = np.arange(1, cap)[None, :] < cnt[:, None]   # (rows beyond an utterance's count hold whatever the buffer held)
+        bad = np.flatnonzero(((starts[:, 1:] < starts[:, :-1]) & live).any(axis=1))
         for b in bad:
             n = int(min(cnt[b], cap))
             if (np.diff(sms[b, :n]) < 0).any():

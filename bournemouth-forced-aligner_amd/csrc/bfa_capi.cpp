@@ -365,7 +365,6 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
 
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT;
     if (row_stats) {
-        if (C < 16) return fail(h, BFA_ERR_UNSUPPORTED, "raw-logit input needs C >= 16 (vectorised softmax order)");
         // rows no kernel prepares (silence fills, frames beyond an utterance, items without a DP) keep this NaN and get
         // their statistics from the first sparse reader that needs them (bfa_math.hpp: row_stats_on_demand).  In the
         // silence-anchored mode on the head widths K0 prepares EVERY row of EVERY utterance (a.row_stats2: k_silprob3) and

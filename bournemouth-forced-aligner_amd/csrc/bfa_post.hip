@@ -78,18 +78,22 @@ __device__ __forceinline__ void extend_pass(int pass, int i, int n, Arr &t, cons
 template <bool RAW>
 __device__ __forceinline__ double seg_mean(const bfa_segment &g, const LpView<RAW> &lp, int Tpad, int C)
 {
-    // :709-714 ; float32 mean of the column slice (accumulated in double, rounded once)
+    // :709-714 ; float32 mean of the strided column slice: torch's cascade sum (bfa_math.hpp: cascade_sum_f32), then / n in float32
     if (g.start < Tpad && g.phoneme < C && g.start < g.end) {
         const int ee = g.end > Tpad ? Tpad : g.end;
-        double acc = 0.0;
-        constexpr int U = 8; // independent (clamped) loads in flight: one element per 268-byte row
-        for (int f0 = g.start; f0 < ee; f0 += U) {
-            float x[U];
-            lp.template at_n<U>(f0, ee - 1, g.phoneme, x);
+        const int n = ee - g.start;
+        constexpr int U = 8; // independent (clamped) loads in flight: one element per 268-byte row (two rows of four)
+        float x[U];
+        int have = -1; // first element of the cached group
+        const float s = cascade_sum_f32(n, [&](int e) -> float {
+            const int g0 = e & ~(U - 1);
+            if (g0 != have) { lp.template at_n<U>(g.start + g0, ee - 1, g.phoneme, x); have = g0; }
+            float v = x[0];
 #pragma unroll
-            for (int u = 0; u < U; ++u) if (f0 + u < ee) acc += (double)exp_cr(x[u]);
-        }
-        return (double)(float)(acc / (double)(ee - g.start));
+            for (int u = 1; u < U; ++u) if ((e & (U - 1)) == u) v = x[u];
+            return exp_cr(v);
+        });
+        return (double)(s / (float)n);
     }
     return 0.001;
 }
@@ -312,15 +316,15 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
         }
         const StagedProb<RAW> pr{lp, sp, off, wlo, whi};
         if (a.do_post && a.extend) {
-            // ---- segment means (core.py:709-714): float32 mean, accumulated in double, rounded once
+            // ---- segment means (core.py:709-714): torch's float32 cascade sum of the strided slice, / n in float32
             for (int i = lane; i < m; i += 64) {
                 const bfa_segment g = st[i];
                 double mean = 0.001;
                 if (g.start < Tpad && g.phoneme < a.C && g.start < g.end) {
                     const int ee = g.end > Tpad ? Tpad : g.end;
-                    double acc = 0.0;
-                    for (int f = g.start; f < ee; ++f) acc += (double)pr.at(i, f, g.phoneme);
-                    mean = (double)(float)(acc / (double)(ee - g.start));
+                    const int n = ee - g.start;
+                    const float sum = cascade_sum_f32(n, [&](int e) -> float { return pr.at(i, g.start + e, g.phoneme); });
+                    mean = (double)(sum / (float)n);
                 }
                 smean[i] = mean;
             }

@@ -891,6 +891,41 @@ int ora_ensure_target_coverage_default(int32_t *seg4, int n, int S)
  * extend_soft_boundaries_func, core.py:682-809.  probs[f,ph].item() is a python float (the
  * float32 value widened), thresholds are python doubles.
  * ---------------------------------------------------------------------------------------- */
+/* torch.Tensor.sum() of a STRIDED float32 1-D view on the CPU (core.py:711: probs[start:end, ph].mean()) -- ATen SumKernel.cpp,
+ * cascade_sum -> scalar_inner_sum -> row_sum -> multi_row_sum<ilp_factor = 4>: the elements as rows of four, four interleaved
+ * float32 accumulators, moved up a level every 16 rows (level_power = max(4, ceil_log2(rows) / 4) = 4 below 2^20 rows; four
+ * levels), levels folded in order, the n % 4 tail added to accumulator 0, then accumulators 1..3.  Pinned against torch
+ * itself: tests/test_oracle_vs_reference_live.py::test_strided_mean_is_torchs (equal bits on every random column). */
+static float ora_cascade_sum_col(const float *lp, long ldT, int s, int e, int ph)
+{
+    float a[4][4] = {{0}};
+    const int n = e - s, rows = n / 4, full = rows & ~15;
+#define EL(i) ora_exp_cr(lp[(long)(s + (i)) * ldT + ph])
+    int i = 0;
+    while (i < full) {
+        for (int j = 0; j < 16; j++, i++)
+            for (int k = 0; k < 4; k++) a[0][k] = a[0][k] + EL(4 * i + k);
+        for (int j = 1; j < 4; j++) {
+            for (int k = 0; k < 4; k++) { a[j][k] = a[j][k] + a[j - 1][k]; a[j - 1][k] = 0.0f; }
+            if ((i & (15 << (4 * j))) != 0) break;
+        }
+    }
+    for (; i < rows; i++)
+        for (int k = 0; k < 4; k++) a[0][k] = a[0][k] + EL(4 * i + k);
+    for (int j = 1; j < 4; j++)
+        for (int k = 0; k < 4; k++) a[0][k] = a[0][k] + a[j][k];
+    for (int el = 4 * rows; el < n; el++) a[0][0] = a[0][0] + EL(el);
+    for (int k = 1; k < 4; k++) a[0][0] = a[0][0] + a[0][k];
+#undef EL
+    return a[0][0];
+}
+
+/* exposed for the pin test: the mean of lp's column slice as ora_extend_soft_boundaries computes it */
+float ora_strided_mean(const float *lp, long ldT, int s, int e, int ph)
+{
+    return ora_cascade_sum_col(lp, ldT, s, e, ph) / (float)(e - s);
+}
+
 int ora_extend_soft_boundaries(const float *lp, long ldT, int Tpad, int C, int32_t *seg4, int n,
                                int boundary_softness)
 {
@@ -903,12 +938,10 @@ int ora_extend_soft_boundaries(const float *lp, long ldT, int Tpad, int C, int32
     for (int i = 0; i < n; i++) { /* :709-714 ; tensor.mean() of float32 -> see note below */
         int ph = seg4[4 * i], s = seg4[4 * i + 1], e = seg4[4 * i + 2];
         if (s < Tpad && ph < C && s < e) {
-            /* torch .mean() on a strided float32 column: sum in float32 via the vectorised
-             * reduction; lengths here are short (<64) where it is a plain sequential... keep
-             * double accumulation and round -- the value only feeds min(mean*1e-3, 1e-3). */
+            /* torch .mean() of the strided float32 column probs[s:e, ph]: ATen's cascade sum (ora_cascade_sum_f32), then
+             * sum / n in float32; .item() widens the float32 */
             int ee = e > Tpad ? Tpad : e;
-            double acc = 0.0; for (int f = s; f < ee; f++) acc += P(f, ph);
-            mean[i] = (double)(float)(acc / (double)(ee - s));
+            mean[i] = (double)(ora_cascade_sum_col(lp, ldT, s, ee, ph) / (float)(ee - s));
         } else mean[i] = 0.001;
     }
     for (int i = 0; i < n; i++) { /* pass 1 :717-735 */

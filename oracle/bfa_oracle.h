@@ -46,6 +46,7 @@ typedef struct {
 /* torch CPU (AVX512 dispatch) numerics, restated: Sleef expf/logf u10 and the
  * vectorised log_softmax reduction order. */
 float ora_expf_u10(float d);
+float ora_strided_mean(const float *lp, long ldT, int s, int e, int ph); /* torch's float32 .mean() of exp(lp)[s:e, ph] (core.py:711) */
 float ora_exp_cr(float x); /* restatement of torch.exp (float32 CPU): float64 exp rounded once */
 void ora_exp_cr_arr(const float *x, float *y, long n);
 float ora_logf_u10(float d);

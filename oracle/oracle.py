@@ -276,6 +276,14 @@ def ensure_target_coverage_default(segs, S):
     return [tuple(int(v) for v in arr[i]) for i in range(m)]
 
 
+def strided_mean(lp, s, e, ph):
+    """float32 mean of exp(lp)[s:e, ph] as torch computes it for that strided view (core.py:711)"""
+    lp = _f32(lp)
+    fn = lib().ora_strided_mean
+    fn.restype = ctypes.c_float
+    return np.float32(fn(_p(lp), ctypes.c_long(lp.shape[1]), int(s), int(e), int(ph)))
+
+
 def extend_soft_boundaries(lp_padded, segs, boundary_softness=3):
     lp = _f32(lp_padded)
     T, C = lp.shape

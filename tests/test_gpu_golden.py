@@ -459,3 +459,71 @@ def test_fused_front_end_equals_two_pass(gpu_device):
         for i in range(B):
             n = int(a[key]["count"][i])
             assert (a[key]["confidence"][i, :n].view(np.int32) == b2[key]["confidence"][i, :n].view(np.int32)).all()
+
+
+def test_soft_boundary_mean_cases_against_reference(gpu_device):
+    """bfa_postprocess (both kernels: probabilities staged in LDS / tuple-per-lane) on tests/golden/softmean_cases.npz: the
+    segment mean of core.py:709-714 is torch's float32 cascade sum of a strided view, and the cases sit on the threshold it
+    feeds (make_golden_softmean.py).  Every case alone and all cases of one family as one padded batch."""
+    import json
+    from bournemouth_forced_aligner_amd import postprocess_batch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "softmean_cases.npz"))
+    meta = json.loads(str(g["meta"]))
+    dev = gpu_device
+    for cap in (4, 500):   # seg_cap 500 x T 460 does not fit k_postconf's LDS staging -> the tuple-per-lane kernel
+        for k, m in enumerate(meta):
+            lp = torch.from_numpy(g[f"s{k}_lp"]).to(dev)[None]
+            tin = g[f"s{k}_in"]
+            segs = torch.zeros((1, cap, 4), dtype=torch.int32, device=dev)
+            segs[0, :len(tin)] = torch.from_numpy(tin).to(dev)
+            cnt = torch.tensor([len(tin)], dtype=torch.int32, device=dev)
+            postprocess_batch(lp, [int(tin[:, 3].max()) + 1], segs, cnt, extend=True, boundary_softness=3)
+            n = int(cnt[0])
+            np.testing.assert_array_equal(segs[0, :n].cpu().numpy(), g[f"s{k}_out"], err_msg=f"cap {cap} case {k} {m}")
+
+
+def test_narrow_widths_from_raw_logits_against_reference(gpu_device):
+    """bfa_align_heads with RAW LOGITS of fewer than sixteen columns (C = 2..15): F.log_softmax (core.py:898-899) fused into
+    the alignment in torch's order for short rows (one exponential after the other), the row statistics it leaves, and the
+    sparse readers on top of them (confidences, soft boundaries; rows nobody prepared get their statistics on demand in the
+    same order).  Against the reference's outputs (tests/golden/make_golden_narrow_raw.py)."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, calculate_confidences_batch, postprocess_batch
+    from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "narrow_raw_cases.npz"))
+    meta = json.loads(str(g["meta"]))
+    assert {m["C"] for m in meta} == {2, 3, 4, 5, 8, 11, 12, 15}
+    for i, m in enumerate(meta):
+        T, S = m["T"], m["S"]
+        pad = 9                                             # padded rows beyond the utterance: statistics on demand
+        x = torch.zeros((1, T + pad, m["C"]), dtype=torch.float32)
+        x[0, :T] = torch.from_numpy(g[f"r{i}_x"])
+        x[0, T:] = torch.randn((pad, m["C"]), generator=torch.Generator().manual_seed(i))
+        x = x.to(gpu_device)
+        tk = torch.from_numpy(g[f"r{i}_tok"].astype(np.int64))[None]
+        au = AlignmentUtils(m["blank"], 0, silence_anchors=0, ignore_noise=True, truly_forced=m["truly_forced"])
+        (res, stats), = align_heads([au], [x], [tk], [T], [S])
+        res.raise_for_status()
+        n = int(res.seg_count[0])
+        np.testing.assert_array_equal(res.segs[0, :n].cpu().numpy(), g[f"r{i}_seg"], err_msg=f"case {i} {m}")
+        np.testing.assert_array_equal(res.frame_phonemes[0, :T].cpu().numpy(), g[f"r{i}_fph"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(res.frame_phonemes_idx[0, :T].cpu().numpy(), g[f"r{i}_fidx"], err_msg=f"case {i}")
+        # the row statistics are log_softmax's: (x - max) - logsum reproduces torch's bits
+        lsm = torch.log_softmax(x[0, :T].cpu(), dim=-1).numpy()
+        st = stats[0, :T].cpu().numpy()
+        mine = (x[0, :T].cpu().numpy() - st[:, :1]) - st[:, 1:2]
+        assert (mine.view(np.int32) == lsm.view(np.int32)).all(), f"case {i}: row statistics"
+        conf, cst = calculate_confidences_batch(x, res.segs, res.seg_count, row_stats=stats)
+        assert int(cst[0]) == 0
+        np.testing.assert_allclose(conf[0, :n].cpu().numpy(), g[f"r{i}_conf"], atol=2e-7, rtol=0, err_msg=f"case {i}")
+        # soft boundaries over the PADDED rows, like the reference (core.py:705): the fixture was made without padding, so
+        # the padded rows are given -30 logits on every target column (their probabilities stay below every threshold)
+        x2 = x.clone()
+        x2[0, T:] = 0.0
+        x2[0, T:, :m["blank"]] = -30.0
+        (res2, stats2), = align_heads([au], [x2], [tk], [T], [S])
+        postprocess_batch(x2, [S], res2.segs, res2.seg_count, extend=True, boundary_softness=3, row_stats=stats2)
+        n2 = int(res2.seg_count[0])
+        ext = res2.segs[0, :n2].cpu().numpy()
+        want = g[f"r{i}_ext"]
+        # (a tuple that reaches the last real frame may extend into the padding only if the padding invites it: it does not)
+        np.testing.assert_array_equal(ext, want, err_msg=f"case {i} {m}: soft boundaries")

@@ -248,3 +248,20 @@ def test_narrow_widths_match_reference(ora):
         np.testing.assert_array_equal(res["frame_idx"][0, :m["T"]], g[f"n{i}_fidx"], err_msg=f"case {i}")
         rc, mod = ora.prepare_emissions(lp, tk, prm)
         assert rc == 0 and (mod.view(np.int32) == g[f"n{i}_mod"].view(np.int32)).all(), f"case {i}"
+
+
+def test_soft_boundary_mean_cases(ora):
+    """tests/golden/softmean_cases.npz (make_golden_softmean.py, from the reference): extend_soft_boundaries_func on tuples
+    whose neighbouring frame sits BETWEEN the threshold torch's float32 cascade mean gives and the one a float64-accumulated
+    mean would give, and on segments long enough for every level of the cascade (core.py:709-735)."""
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "softmean_cases.npz"))
+    meta = json.loads(str(g["meta"]))
+    assert sum(m["kind"] == "adversarial" for m in meta) >= 20 and sum(m["kind"] == "long" for m in meta) >= 10
+    moved = 0
+    for k, m in enumerate(meta):
+        tin = [tuple(int(v) for v in r) for r in g[f"s{k}_in"]]
+        got = np.array(ora.extend_soft_boundaries(g[f"s{k}_lp"], tin, 3), np.int32).reshape(-1, 4)
+        np.testing.assert_array_equal(got, g[f"s{k}_out"], err_msg=f"case {k} {m}")
+        moved += int(not np.array_equal(g[f"s{k}_in"], g[f"s{k}_out"]))
+    assert moved >= 10  # (the cases are not all no-ops)

@@ -175,3 +175,87 @@ def test_threshold_adjacent_exponentials(ora):
     # the correctly rounded restatement keeps the adversarial flip rate low; it cannot be zero without VML itself
     assert flips <= 0.05 * 2 * total
     assert det_flip <= 0.1 * det_total
+
+
+def test_strided_mean_is_torchs(ora):
+    """core.py:711 `probs[start:end, phoneme].mean()`: torch's float32 mean of a strided view is ATen's cascade sum (four
+    interleaved accumulators, a level per sixteen rows), divided by n in float32.  The oracle's restatement gives the same
+    bits as torch on every random column (lengths 1..700: all cascade levels); a running float32 sum and a float64
+    accumulation -- what rounds 1-4 used -- do not."""
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(31)
+    n_cases = n_f64_differs = n_seq_differs = 0
+    for _ in range(1500):
+        n = int(rng.integers(1, 700))
+        lp = np.log(np.clip(rng.random((n + 6, 67)).astype(np.float32) ** 3, 1e-30, 1)).astype(np.float32)
+        ph, s = int(rng.integers(0, 67)), 3
+        probs = torch.from_numpy(ora.exp_cr(lp))          # the oracle's exponentials; torch's own summation on top of them
+        want = np.float32(probs[s:s + n, ph].mean().item())
+        got = ora.strided_mean(lp, s, s + n, ph)
+        assert got.view(np.int32) == want.view(np.int32), (n, got, want)
+        col = probs[s:s + n, ph].numpy()
+        n_f64_differs += int(np.float32(col.astype(np.float64).sum() / n) != want)
+        acc = np.float32(0)
+        for v in col:
+            acc = np.float32(acc + v)
+        n_seq_differs += int(np.float32(acc / np.float32(n)) != want)
+        n_cases += 1
+    print(f"strided mean: {n_cases} columns equal to torch; a float64 accumulation would differ on {n_f64_differs}, a running "
+          f"float32 sum on {n_seq_differs}")
+    assert n_f64_differs > 0 and n_seq_differs > 0
+
+
+def test_sliding_mean_threshold_adjacency(ora):
+    """_detect_silence_segments (forced_alignment.py:503-517): avg = float32(cumsum[i+k-1] - cumsum[i-1]) / k >= 0.9 on
+    P(SIL) = torch.exp(...).  torch.exp differs from the correctly rounded exponential by 1 ulp on ~1 % of arguments; this
+    enumerates windows whose mean sits on the 0.9 line AND that contain such an argument, runs the reference's detector and
+    the oracle's on the same rows, and counts how often the 1-ulp difference flips a silence run.  The count is the honest
+    bound on 'bit-exact boundaries in the silence-anchored mode' for threshold-adjacent posteriors."""
+    import math
+    torch.set_num_threads(1)
+    fa = refload.forced_alignment()
+    # arguments with P(SIL) in [0.6, 1): the frames a window on the 0.9 line is made of
+    rng = np.random.default_rng(77)
+    xs = np.unique((-rng.random(400000) * 0.51).astype(np.float32))
+    mine, tor = ora.exp_cr(xs), torch.exp(torch.from_numpy(xs)).numpy()
+    assert np.abs(mine.view(np.int32).astype(np.int64) - tor.view(np.int32)).max() <= 1
+    differing = xs[mine.view(np.int32) != tor.view(np.int32)]
+    frac = len(differing) / len(xs)
+    assert 0 < frac < 0.05
+    windows = near = flips = 0
+    thr = np.float32(0.9)
+    for k in (3, 10):
+        vd = fa.ViterbiDecoder(blank_id=66, silence_id=0, silence_anchors=k)
+        for xd in differing[:400]:
+            pd_t = float(torch.exp(torch.tensor([xd]))[0])
+            py0 = (float(thr) * k - pd_t) / (k - 1)   # the other k - 1 frames put the window's mean on the line
+            if not (0.0 < py0 < 1.0):
+                continue
+            y0 = np.float32(math.log(py0))
+            ys = [y0]
+            for d in (np.float32(-np.inf), np.float32(np.inf)):
+                y = y0
+                for _ in range(6):
+                    y = np.nextafter(y, d)
+                    ys.append(y)
+            for y in ys:
+                if y > 0:
+                    continue
+                # a run of k frames: one frame with the differing exponential, k - 1 frames at y; no silence anywhere else
+                lp = np.full((k + 8, 67), -20.0, np.float32)
+                lp[4:4 + k, 0] = y
+                lp[4 + k // 2, 0] = xd
+                windows += 1
+                py = float(torch.exp(torch.tensor([y]))[0])
+                mean = (pd_t + (k - 1) * py) / k
+                if abs(mean - float(thr)) > 4 * float(np.spacing(thr)):
+                    continue
+                near += 1
+                ref = vd._detect_silence_segments(torch.from_numpy(lp), sil_prob_threshold=0.9, min_silence_frames=k)
+                got = ora.detect_silence(lp, 0, 0.9, k)
+                flips += int([tuple(int(v) for v in r) for r in ref] != got)
+    print(f"sliding-mean threshold: {len(differing)} of {len(xs)} arguments with P(SIL) in [0.6, 1) ({100 * frac:.2f} %) have "
+          f"exponentials that differ from torch's by 1 ulp; of {windows} windows built around the first 400 of them {near} "
+          f"have a mean within 4 ulp of 0.9, {flips} of those flip a silence run")
+    assert near > 100
+    assert flips <= 0.5 * near
