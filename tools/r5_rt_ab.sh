@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+last() { grep "^{" | tail -1; }
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -x -q -m gpu -k "segment or sil or level2 or realtext or golden or pipeline or soak" 2>&1 | tail -2
+for rep in 1 2; do for lib in build any_old; do
+  if [ $lib = build ]; then unset BFA_HIP_LIBRARY; else export BFA_HIP_LIBRARY=$PWD/bournemouth-forced-aligner_amd/variants/libbfa_$lib.so; fi
+  python bench.py --config realtext --steps 20 --warmup 5 --inflight 1 --parity-sample 128 2>/dev/null | last | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib realtext inflight1 %.4f ms' % d['ms_per_step'], d['parity']['mismatching_utterances'])"
+  python bench.py --config realtext --steps 20 --warmup 5 --parity-sample 0 2>/dev/null | last | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib realtext 3 in flight %.4f ms' % d['ms_per_step'])"
+  python tests/sil_time.py 2>/dev/null | last | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib sil %.4f ms' % d['ms_per_step'])"
+done; done
+unset BFA_HIP_LIBRARY
+bash tools/timeline.sh r5rt2 2 python $PWD/bench.py --config realtext --steps 5 --warmup 2 --settle-ms 0 --min-timed-steps 5 --parity-sample 0 --inflight 1 > gpurun_out/r5_realtext_timeline.txt 2>&1; head -18 gpurun_out/r5_realtext_timeline.txt
+for s in 21 22 23; do timeout 900 python tests/soak.py 100 $s 2>&1 | tail -1; done
