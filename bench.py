@@ -464,7 +464,7 @@ def headline_main(args, rk):
     # HBM bytes of one K1 launch from the PMC passes of tools/profile.sh (committed under profiles/), if it was
     # taken on this workload; FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes
     traffic, tfile = None, None
-    for name in ("r04_k1_traffic.json", "r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
+    for name in ("r05_k1_traffic.json", "r04_k1_traffic.json", "r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and (B, T, S, C) == (4096, 1000, 40, 67) and not args.row_pitch:
             traffic, tfile = json.load(open(tpath))["traffic_bytes_per_launch"], name

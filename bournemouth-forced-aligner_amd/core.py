@@ -23,11 +23,32 @@ _ROW8 = np.dtype([("id", "<i4"), ("start", "<i4"), ("end", "<i4"), ("idx", "<i4"
                   ("start_ms", "<f4"), ("end_ms", "<f4")])
 
 
+_STAGE = {}  # (device, slot) -> pinned uint8 block, grow-only: the staging area of _to_host
+
+
 def _to_host(*tensors):
-    """device tensors -> numpy arrays, one after the other (the first copy waits for the device, the rest are plain copies;
-    pinned staging per call was measured and lost: 27.8 against 6.9 ms per headline call, the pinned blocks of results the
-    caller still holds cannot be recycled)"""
-    return [t.cpu().numpy() for t in tensors]
+    """device tensors -> numpy arrays: the copies go back to back into ONE persistent pinned staging block (one
+    synchronisation, ~50 GB/s instead of a pageable copy each), and the caller gets fresh numpy arrays copied out of it.
+    (Handing out the pinned memory itself was measured and lost: 27.8 against 6.9 ms per headline call -- blocks the caller
+    still holds cannot be recycled and every call allocated fresh pinned memory.)"""
+    dev = next((t.device for t in tensors if t.is_cuda), None)
+    if dev is None:
+        return [t.numpy() for t in tensors]
+    sizes = [(t.numel() * t.element_size() + 255) & ~255 for t in tensors]
+    total = sum(sizes)
+    key = (dev.index, "host")
+    blk = _STAGE.get(key)
+    if blk is None or blk.numel() < total:
+        blk = _STAGE[key] = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+    views, off = [], 0
+    for t, sz in zip(tensors, sizes):
+        tc = t.contiguous()
+        v = blk[off:off + tc.numel() * tc.element_size()].view(tc.dtype).view(tc.shape)
+        v.copy_(tc, non_blocking=True)
+        views.append(v)
+        off += sz
+    torch.cuda.current_stream(dev).synchronize()
+    return [np.array(v.numpy()) for v in views]
 
 
 def _pad_rows(rows, fill):

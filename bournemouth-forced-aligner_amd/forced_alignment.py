@@ -220,26 +220,35 @@ class AlignmentResult:
                 raise RuntimeError(f"item {b}: the class_mask hint excludes what this utterance needs (a K1 class bit is "
                                    f"missing, or no-silence was promised although the target contains the silence id)")
 
-    def to_lists(self):
+    def to_lists(self, check_status=False):
         """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871).
-        ONE kernel packs the valid rows back to back (bfa_pack_results), two copies bring them to the host (the count table,
-        then exactly the packed tuples), one flat list of tuples is cut per utterance (a per-utterance `.tolist()` loop cost
-        76 ms on the 4096-utterance headline batch against 0.35 ms of device time)."""
+        ONE kernel packs the valid rows back to back (bfa_pack_results), ONE pinned copy brings the record to the host, one
+        flat list of tuples is cut per utterance (a per-utterance `.tolist()` loop cost 76 ms on the 4096-utterance headline
+        batch against 0.35 ms of device time).  `check_status`: the per-utterance status rides along in the same round of
+        copies and raise_for_status() runs on it -- one synchronisation per decode_alignments call instead of two."""
         from .sharding import pack_layout, pack_results
         n, cap = int(self.segs.shape[0]), int(self.segs.shape[1])
         bound = n * cap
         rec = pack_results(self.segs, self.seg_count, None, None, n, bound)
         lay = pack_layout(n, bound, False)
         st = torch.cuda.current_stream(rec.device)
+        status_h = None
+        if check_status:
+            status_h = torch.empty((n,), dtype=torch.int32, pin_memory=True)
+            status_h.copy_(self.status, non_blocking=True)
         if lay["words"] * 4 <= (8 << 20):   # one copy of the whole record into pinned memory, one synchronisation
             host = torch.empty((lay["words"],), dtype=torch.int32, pin_memory=True)
             host.copy_(rec, non_blocking=True)
             st.synchronize()
+            if status_h is not None and bool((status_h != 0).any()):
+                self.raise_for_status()
             head = host.numpy()
             total = int(head[1])
             packed = head[lay["tuples"]:lay["tuples"] + 4 * total]
         else:                               # the count table first, then exactly the packed tuples
             head = rec[:lay["tuples"]].cpu().numpy()
+            if status_h is not None and bool((status_h != 0).any()):
+                self.raise_for_status()
             total = int(head[1])
             host = torch.empty((4 * total,), dtype=torch.int32, pin_memory=True)
             host.copy_(rec[lay["tuples"]:lay["tuples"] + 4 * total], non_blocking=True)
@@ -669,8 +678,7 @@ class AlignmentUtils:
             raise ValueError("Phoneme sequences and lengths required for forced alignment")  # :878-879
         res = self.decode_alignments_device(log_probs, true_seqs, pred_lens, true_seqs_lens,
                                             boost_targets=boost_targets, enforce_minimum=enforce_minimum)
-        res.raise_for_status()
-        out = res.to_lists()
+        out = res.to_lists(check_status=True)  # (the reference's exceptions first, from the same round of copies)
         return out if lazy else out.tolist()
 
     def decode_alignments_simple(self, log_probs, true_seqs, pred_lens=None, true_seqs_lens=None, lazy=False):
