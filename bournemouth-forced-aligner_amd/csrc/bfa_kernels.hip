@@ -233,9 +233,9 @@ extern "C" void bfa_launch_dp_nk5(const bfa::AlignArgs *args, unsigned class_mas
 extern "C" void bfa_launch_dp_redo_nk5(const bfa::AlignArgs *args, unsigned class_mask, int mode, hipStream_t stream);
 extern "C" void bfa_launch_dp_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, int grid, bfa::LaunchFan *fan);
 extern "C" void bfa_launch_dp_redo_nk8(const bfa::AlignArgs *args, unsigned class_mask, int mode, hipStream_t stream);
-extern "C" void bfa_launch_dp_big_nk2(const bfa::AlignArgs *args, int grid, hipStream_t stream);
-extern "C" void bfa_launch_dp_big_nk5(const bfa::AlignArgs *args, int grid, hipStream_t stream);
-extern "C" void bfa_launch_dp_big_nk8(const bfa::AlignArgs *args, int grid, hipStream_t stream);
+extern "C" void bfa_launch_dp_big_nk2(const bfa::AlignArgs *args, int grid, hipStream_t stream, int huge);
+extern "C" void bfa_launch_dp_big_nk5(const bfa::AlignArgs *args, int grid, hipStream_t stream, int huge);
+extern "C" void bfa_launch_dp_big_nk8(const bfa::AlignArgs *args, int grid, hipStream_t stream, int huge);
 extern "C" void bfa_launch_backtrace(const bfa::AlignArgs *args, int grid, hipStream_t stream, int wide);
 extern "C" void bfa_launch_backtrace_sel(const bfa::AlignArgs *args, int sel, int fused, int grid, hipStream_t stream, int wide);
 extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t stream);
@@ -383,9 +383,11 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     if (Lmax > 1024) { // paths of more than 1024 states can occur: the workgroup-wide kernel takes them
         const int big_grid = a.B < 1024 ? a.B : 1024;
         hipStream_t bs = fan.pick();
-        if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, bs);
-        else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, bs);
-        else bfa_launch_dp_big_nk8(&a, big_grid, bs);
+        for (int huge = 0; huge <= (Lmax > BIG1_MAX_L ? 1 : 0); ++huge) { // (paths beyond 8 192 states: the sixteen-wave kernel, behind the first)
+            if (nk <= 2) bfa_launch_dp_big_nk2(&a, big_grid, bs, huge);
+            else if (nk <= 5) bfa_launch_dp_big_nk5(&a, big_grid, bs, huge);
+            else bfa_launch_dp_big_nk8(&a, big_grid, bs, huge);
+        }
         if (per_class_k2) bfa_launch_backtrace_sel(&a, K2_BIG, fused_k2 ? 1 : 0, dp_grid, bs, 2);
     }
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);

@@ -155,8 +155,12 @@ __host__ __device__ inline int r_class_for_L(int L)
 // 16g..16g+15, 2 bits each (LSB first).
 constexpr int BFA_FALLBACK_TOO_SHORT = 4; // planner-internal umode: the standard-mode fallback of a segmented candidate is the T < S error
 constexpr int FINAL_NOT_COMPUTED = -2; // Item::final_state until a K1 kernel has taken the item (K2 reports the rest)
-constexpr int BIG_WAVES = 8;
-constexpr int BIG_MAX_L = 1024 * BIG_WAVES;
+constexpr int BIG_WAVES = 8;                  // k_dp_big: paths of 1 025 .. 8 192 states, 16 per lane
+constexpr int BIG1_MAX_L = 1024 * BIG_WAVES;
+// ... and of 8 193 .. 32 768 states (round 5): sixteen wavefronts (a full workgroup) of 32 states per lane, two backpointer
+// dwords per lane and frame, the staged rows in dynamic LDS
+constexpr int BIG2_WAVES = 16, BIG2_R = 32;
+constexpr int BIG_MAX_L = 64 * BIG2_R * BIG2_WAVES;
 __host__ __device__ inline unsigned r_class_bit(int R)
 {
     switch (R) {

@@ -57,7 +57,7 @@ typedef enum {
 #define BFA_ITEM_TOO_SHORT 1   /* T < S : reference raises ValueError("Audio too short to align ...")
                                   (forced_alignment.py:161-165) and aborts the whole call */
 #define BFA_ITEM_BAD_TOKEN 2   /* token id outside [0,C) : reference raises IndexError */
-#define BFA_ITEM_TOO_LARGE 3   /* CTC path longer than this build supports (8192 states = 2047 phonemes in one DP) */
+#define BFA_ITEM_TOO_LARGE 3   /* CTC path longer than this build supports (32 768 states = 8 191 phonemes in one DP at stride 4) */
 #define BFA_ITEM_SEG_OVERFLOW 4 /* more runs than seg_cap: frame outputs are valid, segments truncated */
 #define BFA_ITEM_BAD_HINT 5     /* the class_mask hint excluded what this utterance needs: BFA_HINT_NO_SILENCE_TARGETS
                                    although the target contains silence_id, or a K1 class bit that is missing */

@@ -527,3 +527,49 @@ def test_narrow_widths_from_raw_logits_against_reference(gpu_device):
         want = g[f"r{i}_ext"]
         # (a tuple that reaches the last real frame may extend into the padding only if the padding invites it: it does not)
         np.testing.assert_array_equal(ext, want, err_msg=f"case {i} {m}: soft boundaries")
+
+
+def test_long_paths_against_reference(gpu_device):
+    """CTC paths beyond 1 024 states run in the workgroup-wide kernel: eight waves of 16 states per lane up to 8 192 states,
+    sixteen waves of 32 up to 32 768 (round 5; the reference has no limit, forced_alignment.py:181-192).  Tuples and framewise
+    states against the reference's outputs (tests/golden/make_golden_long.py: L = 2 401, 8 401, 9 001, 12 001, 16 401), alone and
+    as one batch with shorter neighbours; beyond 32 768 states the item is reported, not aligned."""
+    from test_oracle_golden import _long_cases
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    from bournemouth_forced_aligner_amd import _lib
+    batch = []
+    for k, m, lp, tk, g in _long_cases():
+        au = AlignmentUtils(66, 0, silence_anchors=0, ignore_noise=True, truly_forced=m["truly_forced"])
+        lpd = torch.from_numpy(lp).to(gpu_device)
+        res = au.decode_alignments_device(lpd[None], torch.from_numpy(tk.astype(np.int64))[None], [m["T"]], [m["S"]])
+        res.raise_for_status()
+        n = int(res.seg_count[0])
+        np.testing.assert_array_equal(res.segs[0, :n].cpu().numpy(), g[f"g{k}_seg"], err_msg=str(m))
+        np.testing.assert_array_equal(res.frame_phonemes[0, :m["T"]].cpu().numpy(), g[f"g{k}_fph"], err_msg=str(m))
+        np.testing.assert_array_equal(res.frame_phonemes_idx[0, :m["T"]].cpu().numpy(), g[f"g{k}_fidx"], err_msg=str(m))
+        if m["truly_forced"]:
+            batch.append((m, lp, tk, g[f"g{k}_seg"]))
+    # one call holding paths of both big kernels and short neighbours (every class of the launcher at once)
+    import cases
+    rng = np.random.default_rng(5)
+    extra = [cases.planted_case(rng, T, S, C=67, peak=6.0)[:2] for (T, S) in ((300, 40), (1000, 90), (2000, 300))]
+    items = [(lp, tk) for _m, lp, tk, _s in batch] + extra
+    Tm, Sm = max(x[0].shape[0] for x in items), max(len(x[1]) for x in items)
+    LP = np.zeros((len(items), Tm, 67), np.float32)
+    TK = np.full((len(items), Sm), 66, np.int64)
+    for i, (lp, tk) in enumerate(items):
+        LP[i, :lp.shape[0]] = lp
+        TK[i, :len(tk)] = tk
+    au = AlignmentUtils(66, 0, silence_anchors=0, ignore_noise=True, truly_forced=True)
+    res = au.decode_alignments_device(torch.from_numpy(LP).to(gpu_device), torch.from_numpy(TK), [x[0].shape[0] for x in items],
+                                      [len(x[1]) for x in items])
+    res.raise_for_status()
+    for i, (_m, _lp, _tk, want) in enumerate(batch):
+        np.testing.assert_array_equal(res.segs[i, :int(res.seg_count[i])].cpu().numpy(), want, err_msg=f"batched item {i}")
+    # beyond the sixteen-wave kernel: 4 S + 1 > 32 768
+    T, S = 33200, 8200
+    lp = torch.zeros((1, T, 67), device=gpu_device)
+    res = au.decode_alignments_device(lp, torch.ones((1, S), dtype=torch.int64), [T], [S])
+    assert int(res.status[0]) == _lib.ITEM_TOO_LARGE
+    with pytest.raises(RuntimeError):
+        res.raise_for_status()

@@ -265,3 +265,30 @@ def test_soft_boundary_mean_cases(ora):
         np.testing.assert_array_equal(got, g[f"s{k}_out"], err_msg=f"case {k} {m}")
         moved += int(not np.array_equal(g[f"s{k}_in"], g[f"s{k}_out"]))
     assert moved >= 10  # (the cases are not all no-ops)
+
+
+def _long_cases():
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "long_cases.npz"))
+    meta = json.loads(str(g["meta"]))
+    import cases
+    for k, m in enumerate(meta):
+        rng = np.random.default_rng(m["seed"])
+        lp, tk, _ = cases.planted_case(rng, m["T"], m["S"], C=67, peak=m["peak"])
+        assert np.array_equal(tk.astype(np.int32), g[f"g{k}_tok"]) and float(lp.astype(np.float64).sum()) == float(g[f"g{k}_lpsum"][0]), \
+            "the regenerated input differs from the one the fixture was made from"
+        yield k, m, lp, tk, g
+
+
+def test_long_paths_match_reference(ora):
+    """CTC paths of 2 401 .. 16 401 states (tests/golden/make_golden_long.py, from the reference; the reference has no limit,
+    forced_alignment.py:181-192): strides 1 and 4, both final-state rules, one case whose scores reach the sentinel."""
+    n = 0
+    for k, m, lp, tk, g in _long_cases():
+        res = ora.decode_alignments(lp[None], tk[None], [m["T"]], [m["S"]], ora.make_params(66, 0, 0, True, m["truly_forced"]))
+        assert res["status"][0] == 0
+        np.testing.assert_array_equal(np.array(ora.segments_as_lists(res)[0], np.int32).reshape(-1, 4), g[f"g{k}_seg"], err_msg=str(m))
+        np.testing.assert_array_equal(res["frame_ph"][0][:m["T"]], g[f"g{k}_fph"])
+        np.testing.assert_array_equal(res["frame_idx"][0][:m["T"]], g[f"g{k}_fidx"])
+        n += 1
+    assert n >= 5
