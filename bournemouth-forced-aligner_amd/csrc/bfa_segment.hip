@@ -380,9 +380,9 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
                 int n2 = 0;
                 if (lane == 0) n2 = detect_silence(ps + psx, Ts, 0.8f, mf, sc.gsub, sc.gsub_cap);
                 nsub = __builtin_amdgcn_readfirstlane(n2);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 subr = sc.gsub;
             }
             // scratch or anchor pool exhausted (cannot happen with the documented workspace size): flag the utterance
