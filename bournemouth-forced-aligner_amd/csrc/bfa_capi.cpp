@@ -32,6 +32,8 @@ extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t 
                                    int32_t *status, void *stream);
 extern "C" int bfa_launch_pack(const int32_t *segs, int seg_cap, const int32_t *seg_count, const float *conf, const int32_t *gidx,
                                int gidx_base, int n, int n_cap, int tuple_cap, int32_t *out, void *stream);
+extern "C" int bfa_launch_pack16(const int32_t *segs, int seg_cap, const int32_t *seg_count, int n, int n_cap, int tuple_cap,
+                                 int32_t *out, void *stream);
 extern "C" int bfa_launch_index_records(const int32_t *rec, int world, int64_t words, int n_max, int n_total, int32_t *owner,
                                         int32_t *offset, int32_t *count, void *stream);
 extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *p);
@@ -606,6 +608,19 @@ int bfa_pack_results(bfa_handle h, const bfa_segment *segs, int seg_cap, const i
     if (n > 0 && (!segs || !seg_count)) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (((uintptr_t)out & 15) || ((uintptr_t)segs & 15)) return fail(h, BFA_ERR_INVALID_ARGUMENT, "segs / out must be 16-byte aligned");
     const int rc = bfa_launch_pack((const int32_t *)segs, seg_cap, seg_count, conf, global_index, gidx_base, n, n_cap, tuple_cap, out, stream);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
+    return BFA_OK;
+}
+
+int bfa_pack_results16(bfa_handle h, const bfa_segment *segs, int seg_cap, const int32_t *seg_count, int n, int n_cap,
+                       int tuple_cap, int32_t *out, void *stream)
+{
+    if (!h) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
+    if (!out || n < 0 || n_cap < n || tuple_cap < 0 || seg_cap < 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n > 0 && (!segs || !seg_count)) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (((uintptr_t)out & 15) || ((uintptr_t)segs & 15)) return fail(h, BFA_ERR_INVALID_ARGUMENT, "segs / out must be 16-byte aligned");
+    const int rc = bfa_launch_pack16((const int32_t *)segs, seg_cap, seg_count, n, n_cap, tuple_cap, out, stream);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }

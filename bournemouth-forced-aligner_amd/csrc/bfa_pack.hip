@@ -107,6 +107,71 @@ __global__ __launch_bounds__(256) void k_pack(const int4 *__restrict__ segs, int
     }
 }
 
+
+// The same record with 8-byte tuples (phoneme, start, end as uint16, target_idx as int16): for the copy to the host behind
+// decode_alignments, where the 2.6 MB of a 4096-utterance batch's tuples ARE the call's host-side cost (PCIe).  The caller
+// checks that frame counts and ids fit 16 bits.  Word 6 of the header = 1.  Layout as pack_layout with 2 words per tuple.
+__host__ __device__ inline PackLayout pack_layout16(int n_cap, int64_t tuple_cap)
+{
+    PackLayout l = pack_layout(n_cap, 0, 0);
+    l.conf = l.tuples + 2 * tuple_cap;
+    l.words = (l.conf + 3) & ~(int64_t)3;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void k_pack16(const int4 *__restrict__ segs, int seg_cap, const int32_t *__restrict__ seg_count,
+                                                int n, int n_cap, int tuple_cap, int32_t *__restrict__ out)
+{
+    __shared__ int s_part[4];
+    __shared__ int s_off[PACK_UTT + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * PACK_UTT;
+    const PackLayout l = pack_layout16(n_cap, tuple_cap);
+    int acc = 0;
+    const int lim = min(j0, n);
+    for (int i = tid; i < lim; i += 256) acc += min(max(seg_count[i], 0), seg_cap);
+    acc = wave_sum(acc);
+    if (lane == 0) s_part[wave] = acc;
+    const int j = j0 + lane;
+    int cnt = 0;
+    if (wave == 0) {
+        cnt = (j < n) ? min(max(seg_count[j], 0), seg_cap) : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        s_off[lane + 1] = inc;
+        if (lane == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    const int base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    const int block_total = s_off[PACK_UTT];
+    if (wave == 0 && j < n_cap) {
+        out[l.gidx + j] = (j < n) ? j : -1;
+        out[l.count + j] = cnt;
+        out[l.offset + j] = base + s_off[lane];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const int total = base + block_total;
+        out[0] = n; out[1] = min(total, tuple_cap); out[2] = n_cap; out[3] = tuple_cap; out[4] = 0;
+        out[5] = total > tuple_cap; out[6] = 1; out[7] = 0;
+    }
+    uint2 *__restrict__ otup = (uint2 *)(out + l.tuples);
+    for (int q = tid; q < block_total; q += 256) {
+        int lo = 0;
+#pragma unroll
+        for (int step = PACK_UTT / 2; step >= 1; step >>= 1)
+            if (s_off[lo + step] <= q) lo += step;
+        const int k = q - s_off[lo];
+        const int4 v = segs[(int64_t)(j0 + lo) * seg_cap + k];
+        const int dst = base + q;
+        if (dst < tuple_cap)
+            otup[dst] = make_uint2(((uint32_t)v.x & 0xffffu) | ((uint32_t)v.y << 16), ((uint32_t)v.z & 0xffffu) | ((uint32_t)v.w << 16));
+    }
+}
+
 // Receiving side: records [world][words] as k_pack wrote them (one per rank) -> for every global utterance index g its
 // owner (which record), offset (first tuple inside that record's tuple section) and count.  Utterances no record names keep
 // what the caller put there (owner -1 / count 0).
@@ -156,6 +221,17 @@ extern "C" int bfa_launch_pack(const int32_t *segs, int seg_cap, const int32_t *
     const int grid = (n_cap + bfa::PACK_UTT - 1) / bfa::PACK_UTT;
     hipLaunchKernelGGL(bfa::k_pack, dim3(grid > 0 ? grid : 1), dim3(256), 0, (hipStream_t)stream, (const int4 *)segs, seg_cap,
                        seg_count, conf, gidx, gidx_base, n, n_cap, tuple_cap, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int64_t bfa_pack16_words(int n_cap, int64_t tuple_cap) { return bfa::pack_layout16(n_cap, tuple_cap).words; }
+
+extern "C" int bfa_launch_pack16(const int32_t *segs, int seg_cap, const int32_t *seg_count, int n, int n_cap, int tuple_cap,
+                                 int32_t *out, void *stream)
+{
+    const int grid = (n_cap + bfa::PACK_UTT - 1) / bfa::PACK_UTT;
+    hipLaunchKernelGGL(bfa::k_pack16, dim3(grid > 0 ? grid : 1), dim3(256), 0, (hipStream_t)stream, (const int4 *)segs, seg_cap,
+                       seg_count, n, n_cap, tuple_cap, out);
     return (int)hipGetLastError();
 }
 

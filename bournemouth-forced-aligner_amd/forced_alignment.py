@@ -62,6 +62,7 @@ class _Workspace:
 
 
 _ROW4 = np.dtype([("phoneme", "<i4"), ("start", "<i4"), ("end", "<i4"), ("target_idx", "<i4")])
+_ROW4_16 = np.dtype([("phoneme", "<u2"), ("start", "<u2"), ("end", "<u2"), ("target_idx", "<i2")])  # bfa_pack_results16
 
 
 class LazyRowLists(collections.abc.Sequence):
@@ -229,8 +230,26 @@ class AlignmentResult:
         from .sharding import pack_layout, pack_results
         n, cap = int(self.segs.shape[0]), int(self.segs.shape[1])
         bound = n * cap
-        rec = pack_results(self.segs, self.seg_count, None, None, n, bound)
-        lay = pack_layout(n, bound, False)
+        # frame counts, ids and target indices that fit 16 bits (any real batch): 8 bytes per tuple instead of 16 -- the copy
+        # of the tuples is most of what the call costs the host beyond the device step (2.6 MB for the headline batch)
+        small = self.frame_phonemes.shape[1] < 65536 and cap < 32768
+        if small:
+            L = _lib.lib()
+            dev = self.segs.device
+            words = int(L.bfa_pack16_words(n, bound))
+            rec = torch.empty((words,), dtype=torch.int32, device=dev)
+            h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+            with torch.cuda.device(dev):
+                rc = L.bfa_pack_results16(h, self.segs.data_ptr(), cap, self.seg_count.data_ptr(), n, n, bound, rec.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(rc, h, "bfa_pack_results16")
+            lay = pack_layout(n, 0, False)
+            lay["words"] = words
+            tw, row = 2, _ROW4_16   # words per tuple, record type
+        else:
+            rec = pack_results(self.segs, self.seg_count, None, None, n, bound)
+            lay = pack_layout(n, bound, False)
+            tw, row = 4, _ROW4
         st = torch.cuda.current_stream(rec.device)
         status_h = None
         if check_status:
@@ -244,19 +263,19 @@ class AlignmentResult:
                 self.raise_for_status()
             head = host.numpy()
             total = int(head[1])
-            packed = head[lay["tuples"]:lay["tuples"] + 4 * total]
+            packed = head[lay["tuples"]:lay["tuples"] + tw * total]
         else:                               # the count table first, then exactly the packed tuples
             head = rec[:lay["tuples"]].cpu().numpy()
             if status_h is not None and bool((status_h != 0).any()):
                 self.raise_for_status()
             total = int(head[1])
-            host = torch.empty((4 * total,), dtype=torch.int32, pin_memory=True)
-            host.copy_(rec[lay["tuples"]:lay["tuples"] + 4 * total], non_blocking=True)
+            host = torch.empty((tw * total,), dtype=torch.int32, pin_memory=True)
+            host.copy_(rec[lay["tuples"]:lay["tuples"] + tw * total], non_blocking=True)
             st.synchronize()
             packed = host.numpy()
         cnt = head[lay["count"]:lay["count"] + n]
         self._host_record = host  # (the numpy views above live in this pinned block)
-        return LazyRowLists(packed.view(_ROW4).reshape(-1), cnt)
+        return LazyRowLists(packed.view(row).reshape(-1), cnt)
 
 
 class ViterbiDecoder:

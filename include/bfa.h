@@ -315,6 +315,15 @@ int64_t bfa_pack_words(int n_cap, int64_t tuple_cap, int has_conf);
 int bfa_pack_results(bfa_handle h, const bfa_segment *segs, int seg_cap, const int32_t *seg_count, const float *conf,
                      const int32_t *global_index, int gidx_base, int n, int n_cap, int tuple_cap, int32_t *out, void *stream);
 /*
+ * The same record with 8-byte tuples -- phoneme, start, end as uint16, target_idx as int16 -- for the copy to the host behind
+ * decode_alignments' list of lists, where the bytes of the tuples ARE the call's host-side cost.  Only when Tmax, C and Smax
+ * fit 16 bits (the caller checks: BFA_ERR_INVALID_ARGUMENT otherwise is NOT reported, the fields are simply truncated).  No
+ * confidences, gidx = j.  bfa_pack16_words(n_cap, tuple_cap) words; header word 6 = 1; tuples at the same offset, 2 words each.
+ */
+int64_t bfa_pack16_words(int n_cap, int64_t tuple_cap);
+int bfa_pack_results16(bfa_handle h, const bfa_segment *segs, int seg_cap, const int32_t *seg_count, int n, int n_cap,
+                       int tuple_cap, int32_t *out, void *stream);
+/*
  * The receiving side: `records` = world records of `words` int32 each, as bfa_pack_results wrote them (one per rank, e.g. the
  * output of a gather).  For every global utterance index g < n_total named by a record: owner[g] = which record,
  * offset[g] = its first tuple inside that record's tuple section, count[g].  Entries no record names are left untouched.

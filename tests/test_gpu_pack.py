@@ -170,3 +170,26 @@ def test_c4_at_full_size_one_call(ora, gpu_device):
             rows, _ = g.rows(int(gi))
             mism += int(rows.shape[0] != c or not (rows == exp["seg"][k, :c]).all())
     assert mism == 0 and len(sample) >= 500 and int(T[sample].max()) == Tmax
+
+
+def test_to_lists_compact_and_full_records_agree(gpu_device):
+    """AlignmentResult.to_lists(): the 8-byte tuple record (bfa_pack_results16: frame counts / ids that fit 16 bits) and the
+    16-byte one (frame arrays of 65 536 frames or more) give the same lists as the padded arrays they were packed from,
+    incl. target index -1, end == 65 535 and empty utterances."""
+    from bournemouth_forced_aligner_amd.forced_alignment import AlignmentResult
+    dev = gpu_device
+    rng = np.random.default_rng(8)
+    n, cap = 700, 33
+    segs = np.stack([rng.integers(0, 128, size=(n, cap)), rng.integers(0, 65535, size=(n, cap)),
+                     rng.integers(0, 65536, size=(n, cap)), rng.integers(-1, 32767, size=(n, cap))], axis=2).astype(np.int32)
+    segs[3, 0] = [127, 0, 65535, -1]
+    cnt = rng.integers(0, cap + 1, size=n).astype(np.int32)
+    cnt[3] = 5
+    cnt[10:20] = 0
+    want = [[tuple(int(v) for v in segs[b, k]) for k in range(cnt[b])] for b in range(n)]
+    for Tmax in (64, 70000):   # the second: frame arrays too long for 16-bit frame numbers -> the 16-byte record
+        res = AlignmentResult(torch.from_numpy(segs).to(dev), torch.from_numpy(cnt).to(dev), torch.zeros(n, dtype=torch.int32, device=dev),
+                              None, torch.zeros((n, Tmax), dtype=torch.int32, device=dev), None, None, None)
+        got = res.to_lists(check_status=True)
+        assert got.tolist() == want, Tmax
+        assert got[3][0] == (127, 0, 65535, -1) and got[10] == [] and len(got) == n
