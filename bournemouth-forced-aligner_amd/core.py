@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .coverage import ensure_target_coverage
-from .forced_alignment import AlignmentUtils, LazyRowDicts, LazyRowLists, align_heads, rows_as_tuple_lists
+from .forced_alignment import AlignmentUtils, HostLens, LazyRowDicts, LazyRowLists, align_heads, rows_as_tuple_lists
 from .utils import calculate_confidences_batch, convert_to_ms, log_softmax, postprocess_batch
 
 # one row of extract_timestamps_from_segment_batch's result (core.py:939-956)
@@ -114,6 +114,7 @@ class PhonemeTimestampAligner:
         self.enforce_minimum = enforce_minimum
         self.enforce_all_targets = enforce_all_targets
         self.ensure_completeness = ensure_completeness
+        self._shape_pool = None  # two threads for the result shaping of the two heads (extract_timestamps_from_logits)
         self.ignore_noise = ignore_noise
         self.extend_soft_boundaries = extend_soft_boundaries
         self.boundary_softness = boundary_softness
@@ -258,7 +259,7 @@ class PhonemeTimestampAligner:
         dev = self.device
         B = logits_class.shape[0]
         if isinstance(phoneme_sequences, torch.Tensor):
-            ph_seq_lens = (phoneme_sequences != self.blank_class).sum(dim=1).tolist()  # core.py:844
+            ph_seq_lens = (phoneme_sequences != self.blank_class).sum(dim=1).cpu().numpy()  # core.py:844
             ph = phoneme_sequences.to(torch.int32).cpu()
         else:
             ph_seq_lens = [len(s) for s in phoneme_sequences]
@@ -273,13 +274,15 @@ class PhonemeTimestampAligner:
                 if 0 <= int(k) < top:
                     lut[int(k)] = v
             grp = np.where(ids >= 0, lut[np.clip(ids, 0, top - 1)], self.blank_group).astype(np.int32)
-            grp[np.arange(ids.shape[1])[None, :] >= np.asarray(ph_seq_lens)[:, None]] = self.blank_group
+            grp[np.arange(ids.shape[1])[None, :] >= np.asarray(ph_seq_lens, np.int64)[:, None]] = self.blank_group
             gr = torch.from_numpy(grp)
         elif not isinstance(group_sequences, torch.Tensor):
             gr = _pad_rows(group_sequences, self.blank_group)
         else:
             gr = group_sequences.to(torch.int32)
-        spec = [int(x) for x in spectral_lens]
+        # the two length vectors: converted and uploaded once, shared by both heads, the post-DP stages and the shaping
+        spec = HostLens(spectral_lens)
+        ph_seq_lens = HostLens(ph_seq_lens)
         if fused:
             # raw logits of both heads in, log_softmax (core.py:898-899) inside the alignment
             # kernels, both heads from one bfa_align_heads call; the later stages read (logits, row statistics)
@@ -301,6 +304,8 @@ class PhonemeTimestampAligner:
         arrays = {}
         # every head's results in ONE round of copies (pinned, one synchronisation) instead of five blocking ones per head
         flat = _to_host(*[t for _, (res, conf, cstat, _e) in pending for t in (res.status, cstat, res.seg_count, res.segs, conf)])
+        scale = self._ms_scale(spec, wav_lens, start_offset_times, B)
+        jobs = []
         for k, (key, (res, conf, cstat, estimated)) in enumerate(pending):
             st_h, cs_h = flat[5 * k], flat[5 * k + 1]
             if (st_h != 0).any():
@@ -308,7 +313,19 @@ class PhonemeTimestampAligner:
             if (cs_h != 0).any():
                 raise IndexError("confidence pass: phoneme id or start frame out of range")
             res._host3 = flat[5 * k + 2:5 * k + 5]
-            arrays[key] = self._shape_rows(res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays)
+            jobs.append((key, res, conf, estimated))
+        if len(jobs) > 1 and B >= 1024:   # the heads side by side: the shaping is numpy passes over [B, cap] arrays (no GIL)
+            if self._shape_pool is None:
+                import concurrent.futures
+                self._shape_pool = concurrent.futures.ThreadPoolExecutor(max_workers=2)
+            futs = [(key, self._shape_pool.submit(self._shape_rows, res, conf, estimated, spec, wav_lens, start_offset_times,
+                                                  as_arrays, scale)) for key, res, conf, estimated in jobs]
+            for key, f in futs:
+                arrays[key] = f.result()
+        else:
+            for key, res, conf, estimated in jobs:
+                arrays[key] = self._shape_rows(res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays, scale)
+        for _key, res, _c, _e in jobs:
             res._host3 = None
         # (the reference returns a list of B dicts of lists of 8-tuples: here that list builds an utterance's dict and tuples
         # when it is looked at -- 327 680 tuples of the headline batch cost CPython ~85 ms whoever builds them)
@@ -317,7 +334,19 @@ class PhonemeTimestampAligner:
         out = LazyRowDicts(arrays, B)
         return out if lazy else out.tolist()
 
-    def _shape_rows(self, res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays):
+    def _ms_scale(self, spec, wav_lens, start_offset_times, B):
+        """(seconds per frame, start offset) per utterance in the float32 arithmetic of utils.py:126-142 (a 0-dim int64
+        tensor `spectral_length`: reciprocal * duration); shared by the heads of a call"""
+        f32 = np.float32
+        sl = spec.host if isinstance(spec, HostLens) else np.asarray(spec, np.int64)
+        dur = (np.asarray(wav_lens, np.float64) / float(self.resampler_sample_rate)).astype(f32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dpf = np.where(sl > 0, (f32(1) / sl.astype(f32)) * dur, f32(0)).astype(f32)
+        per_item = isinstance(start_offset_times, (list, tuple))
+        off = np.asarray(start_offset_times if per_item else [start_offset_times] * B, np.float64).astype(f32)
+        return dpf, off
+
+    def _shape_rows(self, res, conf, estimated, spec, wav_lens, start_offset_times, as_arrays, scale=None):
         """core.py:939-956 for one head and the whole batch at once: convert_to_ms in the float32 tensor arithmetic
         the reference ends up in (utils.py:128-146 with a 0-dim tensor `spectral_length`), then the rows as the
         reference's 8-tuples -- or, with `as_arrays`, as padded numpy arrays (no per-row Python objects: on a
@@ -325,12 +354,7 @@ class PhonemeTimestampAligner:
         f32 = np.float32
         cnt, segs, cf = res._host3 if getattr(res, "_host3", None) is not None else _to_host(res.seg_count, res.segs, conf)
         B, cap = segs.shape[0], segs.shape[1]
-        sl = np.asarray(spec, np.int64)
-        dur = (np.asarray(wav_lens, np.float64) / float(self.resampler_sample_rate)).astype(f32)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            dpf = np.where(sl > 0, (f32(1) / sl.astype(f32)) * dur, f32(0)).astype(f32)
-        per_item = isinstance(start_offset_times, (list, tuple))
-        off = np.asarray(start_offset_times if per_item else [start_offset_times] * B, np.float64).astype(f32)
+        dpf, off = scale if scale is not None else self._ms_scale(spec, wav_lens, start_offset_times, B)
         # start and end frames in one pass: (offset + frame * seconds_per_frame) * 1000, each operation rounded to float32
         ms = segs[:, :, 1:3].astype(f32)
         ms *= dpf[:, None, None]

@@ -24,9 +24,40 @@ def _device_of(t):
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class HostLens:
+    """A length vector known on the host, converted ONCE (int64 numpy for the class hint, int32 device tensor for the
+    kernels): both heads of a call, the post-DP stages and the result shaping share it instead of converting the caller's
+    list of B python ints every time (0.15 ms per conversion at B = 4096)."""
+    __slots__ = ("host", "_dev")
+
+    def __init__(self, x):
+        if isinstance(x, torch.Tensor):
+            x = x.cpu().numpy()
+        self.host = np.ascontiguousarray(np.asarray(x, dtype=np.int64).reshape(-1))
+        self._dev = {}
+
+    def __len__(self):
+        return self.host.shape[0]
+
+    def __iter__(self):
+        return iter(self.host.tolist())
+
+    def __getitem__(self, i):
+        v = self.host[i]
+        return int(v) if np.ndim(v) == 0 else v.tolist()
+
+    def dev(self, device):
+        t = self._dev.get(device)
+        if t is None:
+            t = self._dev[device] = torch.from_numpy(self.host.astype(np.int32)).to(device, non_blocking=True)
+        return t
+
+
 def _as_i32(x, device, n=None):
     if x is None:
         return None
+    if isinstance(x, HostLens):
+        return x.dev(device)
     if not isinstance(x, torch.Tensor):
         x = torch.as_tensor(np.asarray(x))
     return x.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
@@ -36,6 +67,8 @@ def _host_array(x):
     """x as a numpy array if it lives on the host (list / ndarray / CPU tensor), else None (no device sync)."""
     if x is None:
         return None
+    if isinstance(x, HostLens):
+        return x.host
     if isinstance(x, torch.Tensor):
         return x.numpy() if x.device.type == "cpu" else None
     try:
