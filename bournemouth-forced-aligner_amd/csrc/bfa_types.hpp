@@ -58,6 +58,28 @@ constexpr int ONE_MAX_BATCH = 1024; // largest single-class call that takes the 
 constexpr int MIX_MIN_BATCH = BFA_MIX_MIN_BATCH; // a lone utterance keeps the per-class kernels (its dead tail runs segment-parallel there); 64 until the
                                                  // end of round 4: calls of 4-48 sentences took 1.3-1.7 x as long through the class kernels (profiles/r04_latency_mixed.txt)
 
+// An item record every lane of a wave has loaded from the same address is wave-uniform, but the compiler cannot know (the
+// load is a vector load whenever the kernel also writes the item list): everything derived from it -- frame counts, loop
+// bounds, the walk's state and frame masks -- then lives in vector registers and is computed by the VALU with exec-mask
+// branches.  Passing the fields through v_readfirstlane once puts them, and what follows from them, on the scalar unit.
+#ifndef BFA_UNIFORM_ITEM
+#define BFA_UNIFORM_ITEM 1 // (A/B: 0 = the records as loaded)
+#endif
+__device__ __forceinline__ Item uniform_item(const Item &v)
+{
+#if !BFA_UNIFORM_ITEM
+    return v;
+#endif
+    auto u = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+    Item it;
+    it.kind = u(v.kind); it.utt = u(v.utt); it.row0 = u(v.row0); it.Ts = u(v.Ts); it.tok0 = u(v.tok0); it.nt = u(v.nt);
+    it.stride = u(v.stride); it.L = u(v.L); it.bw = u(v.bw); it.out0 = u(v.out0); it.nout = u(v.nout);
+    it.pad_left = u(v.pad_left); it.final_state = u(v.final_state); it.anch_off = u(v.anch_off);
+    it.bp_off = ((int64_t)u((int)(v.bp_off >> 32)) << 32) | (uint32_t)u((int)(v.bp_off & 0xffffffffll));
+    it.win = u(v.win); it.split = u(v.split); it.xw = u(v.xw); it.t_tail = u(v.t_tail);
+    return it;
+}
+
 // one wavefront's candidates for the final-state rule (forced_alignment.py:656-682) when a DP is spread over
 // several wavefronts (k_dp_big, k_dp5): rightmost / best state above the sentinel, best of all, dp[L-1], dp[L-2]
 struct BigFinal {
