@@ -552,7 +552,6 @@ int bfa_postprocess(bfa_handle h, const float *logp, float *row_stats, int64_t s
     DeviceGuard guard(h);
     if (!logp || !S_len || !segs || !seg_count) return fail(h, BFA_ERR_INVALID_ARGUMENT, "null pointer argument");
     if (B <= 0 || Tmax <= 0 || C <= 0 || seg_cap <= 0) return fail(h, BFA_ERR_INVALID_ARGUMENT, "non-positive size");
-    if (seg_cap > 6500) return fail(h, BFA_ERR_UNSUPPORTED, "seg_cap > 6500 in bfa_postprocess (24 bytes of LDS per tuple)");
     // core.py:699-701 : python `10.0 ** -n` is libm pow on doubles
     const double th1 = std::pow(10.0, -3.0), th2 = std::pow(10.0, -(double)boundary_softness);
     if (staged_post()) {

@@ -98,22 +98,33 @@ __device__ __forceinline__ double seg_mean(const bfa_segment &g, const LpView<RA
     return 0.001;
 }
 
-template <bool RAW>
+// BIG = false: the utterance's tuples and their means live in LDS (24 bytes per tuple slot: seg_cap <= POST_LDS_CAP).
+// BIG = true (more slots than that -- paths of thousands of tokens, or seg_cap = Tmax + 1 of a long recording): the tuples
+// stay where they are, in the caller's array, and only the MEANS go through LDS, POST_CHUNK tuples at a time.  The means
+// belong to the tuples as the DP left them (core.py:709-714 runs before the passes) and passes 1 and 2 both need them, so
+// the chunks are interleaved: means and pass 1 of chunk k+1, THEN pass 2 of chunk k -- pass 1 only writes starts and reads
+// the end of the tuple before (which pass 2 of that chunk has not touched yet), pass 2 only writes ends and reads the start
+// of the tuple after (whose pass 1 is done).  Passes 3 and 4 need no means: plain sweeps.
+constexpr int POST_LDS_CAP = 6500;
+constexpr int POST_CHUNK = 2048;
+
+template <bool RAW, bool BIG>
 __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    double *smean = (double *)dyn_lds;                                   // [seg_cap]
-    bfa_segment *st = (bfa_segment *)(dyn_lds + (size_t)a.seg_cap * 8);  // [seg_cap]
+    double *smean = (double *)dyn_lds;                                   // [seg_cap] (BIG: [2][POST_CHUNK])
     const int lane = threadIdx.x & 63;
     const double th1 = a.th1, th2 = a.th2;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         bfa_segment *sg = a.segs + (int64_t)b * a.seg_cap;
+        bfa_segment *st = BIG ? sg : (bfa_segment *)(dyn_lds + (size_t)a.seg_cap * 8);  // [seg_cap]
         const LpView<RAW> lp{a.logp + (int64_t)b * a.strideB, a.strideT,
                              RAW ? a.row_stats + 2 * (int64_t)b * a.Tmax : nullptr, a.C};
         int n = a.seg_count[b];
         if (n > a.seg_cap) n = a.seg_cap;
         const int S = a.S_len[b];
         // ---- ensure_target_coverage (default): drop idx == -1 or idx >= S (core.py:488-513)
+        // (BIG compacts in place: slot m + rank <= base + lane, and the stores of a batch depend on its loads)
         int m = 0;
         for (int base = 0; base < n; base += 64) {
             const int i = base + lane;
@@ -140,14 +151,38 @@ __global__ __launch_bounds__(64) void k_postprocess(PostArgs a)
             post_sync();
         }
         if (a.extend) {
-            for (int i = lane; i < m; i += 64) smean[i] = seg_mean(st[i], lp, a.Tmax, a.C);
-            post_sync();
-            for (int pass = 1; pass <= 4; ++pass) {
-                for (int i = lane; i < m; i += 64) extend_pass(pass, i, m, st, lp, a.Tmax, a.C, th1, th2, smean);
+            if constexpr (!BIG) {
+                for (int i = lane; i < m; i += 64) smean[i] = seg_mean(st[i], lp, a.Tmax, a.C);
                 post_sync();
+                for (int pass = 1; pass <= 4; ++pass) {
+                    for (int i = lane; i < m; i += 64) extend_pass(pass, i, m, st, lp, a.Tmax, a.C, th1, th2, smean);
+                    post_sync();
+                }
+            } else {
+                const int n_chunks = (m + POST_CHUNK - 1) / POST_CHUNK;
+                for (int k = 0; k <= n_chunks; ++k) {
+                    if (k < n_chunks) { // means + pass 1 of chunk k
+                        const int c0 = k * POST_CHUNK, c1 = min(m, c0 + POST_CHUNK);
+                        double *mk = smean + (k & 1) * POST_CHUNK - c0; // indexed by the tuple
+                        for (int i = c0 + lane; i < c1; i += 64) mk[i] = seg_mean(st[i], lp, a.Tmax, a.C);
+                        post_sync();
+                        for (int i = c0 + lane; i < c1; i += 64) extend_pass(1, i, m, st, lp, a.Tmax, a.C, th1, th2, mk);
+                        post_sync();
+                    }
+                    if (k > 0) { // pass 2 of chunk k - 1
+                        const int c0 = (k - 1) * POST_CHUNK, c1 = min(m, c0 + POST_CHUNK);
+                        const double *mk = smean + ((k - 1) & 1) * POST_CHUNK - c0;
+                        for (int i = c0 + lane; i < c1; i += 64) extend_pass(2, i, m, st, lp, a.Tmax, a.C, th1, th2, mk);
+                        post_sync();
+                    }
+                }
+                for (int pass = 3; pass <= 4; ++pass) {
+                    for (int i = lane; i < m; i += 64) extend_pass(pass, i, m, st, lp, a.Tmax, a.C, th1, th2, smean);
+                    post_sync();
+                }
             }
         }
-        for (int i = lane; i < m; i += 64) sg[i] = st[i];
+        if constexpr (!BIG) for (int i = lane; i < m; i += 64) sg[i] = st[i];
         if (lane == 0) a.seg_count[b] = m;
         post_sync();
     }
@@ -481,13 +516,20 @@ extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64
     PostArgs a;
     a.logp = logp; a.row_stats = row_stats; a.strideB = strideB; a.strideT = strideT; a.B = B; a.Tmax = Tmax; a.C = C; a.S_len = S_len;
     a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.extend = extend; a.th1 = th1; a.th2 = th2;
+    const unsigned grid = B < 65536 ? B : 65536;
+    if (seg_cap > POST_LDS_CAP) { // tuples in place, means through LDS in chunks (k_postprocess<.., BIG>)
+        const size_t lds = 2 * (size_t)POST_CHUNK * 8;
+        if (row_stats) hipLaunchKernelGGL((k_postprocess<true, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
+        else hipLaunchKernelGGL((k_postprocess<false, true>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
+        return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)seg_cap * (8 + sizeof(bfa_segment));
     if (lds > 48 * 1024) { // beyond the default dynamic-LDS limit (seg_cap = Tmax + 1 with ignore_noise = False)
-        (void)hipFuncSetAttribute((const void *)k_postprocess<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_postprocess<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_postprocess<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_postprocess<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (row_stats) hipLaunchKernelGGL(k_postprocess<true>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL(k_postprocess<false>, dim3(B < 65536 ? B : 65536), dim3(64), lds, (hipStream_t)stream_, a);
+    if (row_stats) hipLaunchKernelGGL((k_postprocess<true, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((k_postprocess<false, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
 

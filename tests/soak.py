@@ -114,7 +114,7 @@ def run(nb=200, seed=1, dev=None):
                       f"simple={simple} boost={boost} enf={enf} min_prob={min_prob} hint={hint} status={st[b]}/{exp['status'][b]}", flush=True)
         # ---- post-DP stages on the GPU's own tuples: confidences (utils.py:70-113), then ensure_target_coverage
         # (default) + extend_soft_boundaries (core.py:925-931)
-        if (st == 0).all() and n > 0 and lp.shape[1] + 1 <= 6000:  # (bfa_postprocess: <= 6 500 tuple slots per utterance)
+        if (st == 0).all() and n > 0:
             from bournemouth_forced_aligner_amd import calculate_confidences_batch
             from bournemouth_forced_aligner_amd.utils import postprocess_batch
             lpd = lpd_in

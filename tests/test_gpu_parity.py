@@ -590,14 +590,23 @@ def test_staged_and_tuple_per_lane_post_stages_agree(ora, gpu_device):
     assert (res.status.cpu().numpy() == 0).all()
     cap = res.segs.shape[1]
     big = 2000  # 68 bytes of LDS per tuple (records + 2 K staged cells): > 60 KB, the staging kernel declines; <= 6500
+    huge = 7000  # > 6500 slots: k_postprocess keeps the tuples in place and takes the means through LDS in chunks
     Sd = torch.from_numpy(np.asarray(S_len, np.int32))
     for extend, soft in ((True, 3), (True, 6), (False, 3)):
         s1, n1 = res.segs.clone(), res.seg_count.clone()
         s2 = torch.zeros((lp.shape[0], big, 4), dtype=torch.int32, device=gpu_device)
         s2[:, :cap] = res.segs
         n2 = res.seg_count.clone()
+        s3 = torch.zeros((lp.shape[0], huge, 4), dtype=torch.int32, device=gpu_device)
+        s3[:, :cap] = res.segs
+        n3 = res.seg_count.clone()
         postprocess_batch(lpd, Sd, s1, n1, extend=extend, boundary_softness=soft)
         postprocess_batch(lpd, Sd, s2, n2, extend=extend, boundary_softness=soft)
+        postprocess_batch(lpd, Sd, s3, n3, extend=extend, boundary_softness=soft)
+        torch.cuda.synchronize()
+        assert torch.equal(n1, n3)
+        for b in range(lp.shape[0]):
+            assert torch.equal(s1[b, :int(n1[b])], s3[b, :int(n3[b])]), f"in-place rows item {b} extend={extend}"
         c1, st1 = calculate_confidences_batch(lpd, s1, n1)
         c2, st2 = calculate_confidences_batch(lpd, s2, n2)
         torch.cuda.synchronize()
@@ -616,6 +625,68 @@ def test_staged_and_tuple_per_lane_post_stages_agree(ora, gpu_device):
             if ext:
                 rc, oc, _, _ = ora.confidences(lp[b], ext)
                 assert rc == 0 and (b1[b, :n[b]].view(np.int32) == oc.view(np.int32)).all(), f"oracle confidences item {b}"
+
+
+def test_postprocess_of_thousands_of_tuples(ora, gpu_device):
+    """bfa_postprocess beyond 6 500 tuple slots per utterance (a path of thousands of tokens, or seg_cap = Tmax + 1 of a
+    long recording): the tuples stay in the caller's array and the segment means go through LDS 2 048 tuples at a time,
+    pass 2 of a chunk behind pass 1 of the next (bfa_post.hip: k_postprocess<.., BIG>).  Utterances of 1 .. 9 000 tuples
+    (below one chunk, exactly two chunks, two chunks + 1, four and a half) whose neighbouring frames sit around both
+    thresholds, tuples to drop among them (idx == -1, idx >= S), log-probs and raw logits: rows equal to the oracle's
+    ensure_target_coverage + extend_soft_boundaries, softness 3 and 5."""
+    from bournemouth_forced_aligner_amd.utils import postprocess_batch
+    from bournemouth_forced_aligner_amd import _lib
+    rng = np.random.default_rng(90210)
+    C = 23
+    counts = [1, 700, 4096, 4097, 9000, 2048]
+    cap = 9300
+    T = 4 * 9000 + 200
+    B = len(counts)
+    lp = np.log(np.clip(rng.random((B, T, C)).astype(np.float32) ** 8, 1e-7, 1.0)).astype(np.float32)
+    lp -= np.log(np.exp(lp.astype(np.float64)).sum(-1, keepdims=True)).astype(np.float32)   # (roughly) normalised
+    segs = np.zeros((B, cap, 4), np.int32)
+    cnt = np.zeros(B, np.int32)
+    S_len = np.zeros(B, np.int32)
+    for b, n in enumerate(counts):
+        t, rows = int(rng.integers(0, 30)), []
+        for i in range(n):
+            d = int(rng.integers(1, 4))
+            ph = int(rng.integers(0, C - 1))
+            idx = i if rng.random() > 0.03 else (-1 if rng.random() < 0.5 else n + 5)
+            rows.append((ph, t, t + d, idx))
+            lp[b, t:t + d, ph] = np.log(rng.random(d).astype(np.float32) * 0.9 + 0.05)
+            # the frames around the tuple: probabilities around mean * 1e-3 and 10 ** -softness
+            g = int(rng.integers(0, 4))
+            lp[b, t + d:t + d + g, ph] = np.log((10.0 ** rng.uniform(-5.5, -2.0, g)).astype(np.float32))
+            t += d + g
+        segs[b, :n] = np.array(rows, np.int32)
+        cnt[b] = n
+        S_len[b] = n
+    raw = lp + rng.normal(0, 3, (B, T, 1)).astype(np.float32)     # raw logits with the same log-softmax up to rounding
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+    for use_raw in (False, True):
+        if use_raw:
+            # the row statistics (max, log-sum) a fused call leaves; the targets of that call do not matter here
+            x = torch.from_numpy(raw).to(gpu_device)
+            tk = torch.from_numpy(rng.integers(1, C - 1, (B, 12)).astype(np.int64))
+            (_, stats), = align_heads([AlignmentUtils(C - 1, 0)], [x], [tk], [T] * B, [12] * B)
+            ref_lp = torch.log_softmax(torch.from_numpy(raw), dim=-1).numpy()   # core.py:898-899
+        else:
+            x, stats, ref_lp = torch.from_numpy(lp).to(gpu_device), None, lp
+        for soft in (3, 5):
+            sd = torch.from_numpy(segs).to(gpu_device)
+            nd = torch.from_numpy(cnt).to(gpu_device)
+            postprocess_batch(x, torch.from_numpy(S_len), sd, nd, extend=True, boundary_softness=soft, row_stats=stats)
+            torch.cuda.synchronize()
+            got, gn = sd.cpu().numpy(), nd.cpu().numpy()
+            for b in range(B):
+                tup = [tuple(int(v) for v in r) for r in segs[b, :cnt[b]]]
+                cov = ora.ensure_target_coverage_default(tup, int(S_len[b]))
+                ext = ora.extend_soft_boundaries(ref_lp[b], cov, soft) if cov else []
+                assert gn[b] == len(ext), (b, gn[b], len(ext))
+                assert [tuple(int(v) for v in r) for r in got[b, :gn[b]]] == [tuple(e[:4]) for e in ext], f"item {b} soft {soft} raw {use_raw}"
+            assert any(not np.array_equal(got[b, :gn[b]], np.array([r for r in segs[b, :cnt[b]] if 0 <= r[3] < S_len[b]], np.int32).reshape(-1, 4)) for b in range(B))  # something was extended
 
 
 def test_one_kernel_small_batch_path(ora, gpu_device):
