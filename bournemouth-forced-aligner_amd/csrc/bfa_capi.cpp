@@ -152,8 +152,9 @@ size_t carve_all(Carve &c, int B, int Tmax, int Smax, int C, const bfa_params *p
     auto bp = c.take<uint32_t>((size_t)B * (size_t)l.bp_per_utt);
     auto mix_key = c.take<uint8_t>((size_t)B);   // mixed-length calls: cost bucket per utterance (k_plan) ...
     auto mix_order = c.take<int32_t>((size_t)B); // ... and the utterance slots by decreasing cost (k_order -> k_mix)
+    auto piece_list = c.take<int32_t>(seg ? (size_t)bfa::PIECE_BUCKETS * (size_t)l.item_cap : 1); // silence-anchored mode: the pieces by length bucket
     if (a) {
-        a->mix_key = mix_key; a->mix_order = mix_order;
+        a->mix_key = mix_key; a->mix_order = mix_order; a->piece_list = piece_list;
         a->items = items; a->item_cap = l.item_cap; a->counters = counters; a->umask = umask; a->uT = uT; a->uS = uS;
         a->umode = umode; a->anchor = anchor; a->anchor_per_utt = anchor_per_utt; a->psil = psil; a->cand = cand;
         a->row_stats2 = reuse ? row_stats2 : nullptr; a->ucand = ucand;

@@ -407,7 +407,13 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         it.out0 = w;
         it.nout = min(n, max(0, T - w));
         w += n;
-        if (writer) a.items[slot] = it;
+        if (writer) {
+            a.items[slot] = it;
+            if (it.kind == ITEM_DP) { // k_dp4_any starts the long pieces first (AlignArgs::piece_list)
+                const int bk = piece_bucket(it.Ts, a.Tmax);
+                a.piece_list[(int64_t)bk * a.item_cap + atomicAdd(&a.counters[PIECE_CNT0 + bk], 1)] = slot;
+            }
+        }
         ++slot;
     }
     {   // :461-464 pad with blank / -1 up to T (also fills unused reserved slots)

@@ -50,6 +50,12 @@ struct Item {
     int32_t t_tail;    // exact-window items: > 0 = K1 left the serial loop at this frame (the scores were dead): k_dp4x_tail writes the rest
 };
 constexpr int XW_FAST = 0, XW_EXACT = 1, XW_REDO = 2, XW_REDONE = 3;
+constexpr int PIECE_BUCKETS = 12, PIECE_CNT0 = 4; // AlignArgs::piece_list: length buckets, their counters in counters[4 .. 15]
+__host__ __device__ inline int piece_bucket(int Ts, int Tmax)
+{
+    const int b = (int)(((int64_t)Ts * PIECE_BUCKETS) / (Tmax + 8));
+    return b < 0 ? 0 : (b >= PIECE_BUCKETS ? PIECE_BUCKETS - 1 : b);
+}
 constexpr uint32_t XWIN_REDO = 0x100u, XWIN_MIX = 0x200u;
 constexpr int ONE_MAX_BATCH = 1024; // largest single-class call that takes the one-kernel path (k_one; 8192: 0.62 ms against 0.32 + 0.06 for the headline batch)
 #ifndef BFA_MIX_MIN_BATCH
@@ -142,6 +148,10 @@ struct AlignArgs {
     int32_t k2_windows;     // launcher: the window items are walked behind the window kernels on their stream (K2_WIN)
     uint8_t *mix_key;       // [B] mixed-length calls (DevParams::xwin_mask & XWIN_MIX): 255 - cost bucket of the utterance (k_plan)
     int32_t *mix_order;     // [B] ... the utterance slots by decreasing cost (k_order), the work list of k_mix
+    // silence-anchored mode: the DP pieces by length, longest first, for k_dp4_any.  k_plan_seg appends a piece's item index to
+    // the list of its length bucket (counters[PIECE_CNT0 + bucket] entries in piece_list[bucket * item_cap ..]); workgroup
+    // B + k of k_dp4_any takes the k-th entry counting from the longest bucket down (bfa_dp4.inc: any_item)
+    int32_t *piece_list;
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_XWIN = 5, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
 constexpr int K2_NARROW = 64; // | (class bits of the merged narrow full-layout classes << 8): K2_WIN + those classes (k_dp4w_any)
