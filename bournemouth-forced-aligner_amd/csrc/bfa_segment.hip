@@ -11,6 +11,7 @@
 //
 // All control-flow arithmetic is the reference's: python floats are doubles, int() truncates,
 // torch.cumsum(float32) is a float64 running sum rounded to float32 at every element.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "bfa_softmax.hpp"
@@ -109,6 +110,14 @@ __device__ int detect_silence_w(const float *ps, int Tx, float thr, int k, int32
             const float x = xn;
             xn = (base + 64 + lane < Tx) ? ps[base + 64 + lane] : 0.0f; // the next slice is in flight during this one's chain
             double acc = carry;
+#ifdef BFA_EXP_PLAN_SCAN // (timing experiment: the prefix sums of a slice as a log-step scan -- NOT torch's order of additions)
+            {
+                double v = (double)x;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_up(v, d); if (lane >= d) v += o; }
+                acc = carry + v;
+            }
+#else
             // Step j: the lanes >= j add x[j].  The lane set shrinks by one lane per step, so it is kept in EXEC itself and
             // shifted by the scalar unit; a step is three vector instructions (two broadcasts, one add).  Written out by
             // the compiler from `acc += (lane >= j) ? x[j] : 0` it was eight: the 64 lane masks did not fit the scalar
@@ -127,6 +136,7 @@ __device__ int detect_silence_w(const float *ps, int Tx, float thr, int k, int32
 #undef BFA_CS_FIRST
 #undef BFA_CS_STEP
             }
+#endif
             if (base + lane < Tx) cs[base + lane] = (float)acc;
             const long long bits = __builtin_bit_cast(long long, acc);
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 63);
@@ -181,6 +191,7 @@ struct PlanScratch {
     SegRec *segs;
     int aud_cap;
     float *cs; // LDS, cooperative mode only
+    int32_t *pbk; // LDS, cooperative mode only: the length bucket of every emitted piece (-1: not a DP piece)
     int32_t *gsub; // cooperative mode: the utterance's global sub-silence scratch, for a piece whose runs overflow the LDS array
     int gsub_cap;
 };
@@ -205,6 +216,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
     int32_t *groups = sc.groups, *aud = sc.aud, *sub = sc.sub, *match = sc.match;
     SegRec *segs = sc.segs;
     const int aud_cap = sc.aud_cap;
+    int32_t *const pbk = sc.pbk;
 
     bool ok = true;
     // ---- _find_target_sil_groups :203-224
@@ -407,14 +419,38 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         it.out0 = w;
         it.nout = min(n, max(0, T - w));
         w += n;
+        // k_dp4_any starts the long pieces first (AlignArgs::piece_list: one list per length bucket).  COOP: the bucket of
+        // every piece is parked in LDS and the lists are appended to after the loop -- ONE returning atomic per bucket and
+        // utterance, all of them in flight together, instead of one memory round trip per piece in the serial chain
+        const int bk = (it.kind == ITEM_DP) ? piece_bucket(it.Ts, a.Tmax) : -1;
+        if (COOP) { if (lane == 0) pbk[slot - base] = bk; }
         if (writer) {
             a.items[slot] = it;
-            if (it.kind == ITEM_DP) { // k_dp4_any starts the long pieces first (AlignArgs::piece_list)
-                const int bk = piece_bucket(it.Ts, a.Tmax);
-                a.piece_list[(int64_t)bk * a.item_cap + atomicAdd(&a.counters[PIECE_CNT0 + bk], 1)] = slot;
-            }
+            if (!COOP && bk >= 0) a.piece_list[(int64_t)bk * a.item_cap + atomicAdd(&a.counters[PIECE_CNT0 + bk], 1)] = slot;
         }
         ++slot;
+    }
+    if (COOP) {
+        const int nemit = slot - base; // (<= 2 * groups_cap + 1 entries of pbk)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j0 = 0; j0 < nemit; j0 += 64) {
+            const int j = j0 + lane;
+            const int mybk = (j < nemit) ? pbk[j] : -1;
+            int cnt_mine = 0;   // lane k: how many pieces of this chunk go to bucket k
+            int rank = 0;       // this lane's piece: its position among the chunk's pieces of the same bucket
+#pragma unroll
+            for (int k = 0; k < PIECE_BUCKETS; ++k) {
+                const unsigned long long m = __ballot(mybk == k);
+                if (lane == k) cnt_mine = __builtin_popcountll(m);
+                if (mybk == k) rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            }
+            int start_mine = 0;
+            if (lane < PIECE_BUCKETS && cnt_mine > 0) start_mine = atomicAdd(&a.counters[PIECE_CNT0 + lane], cnt_mine);
+            const int st = __shfl(start_mine, mybk < 0 ? 0 : mybk);
+            if (mybk >= 0) a.piece_list[(int64_t)mybk * a.item_cap + st + rank] = base + j;
+        }
     }
     {   // :461-464 pad with blank / -1 up to T (also fills unused reserved slots)
         Item it;
@@ -438,14 +474,23 @@ constexpr int PLAN_LDS_SILS = 128;  // audio silences / sub-silences (pairs)
 constexpr int PLAN_LDS_GROUPS = 64; // target SIL groups / matches (pairs)
 
 // `lds_frames` (a multiple of 64, <= PLAN_LDS_FRAMES): frames of the staged cumulative sums -- sized by the batch's Tmax,
-// so that a batch of short utterances keeps more planners resident per CU (they are latency chains, LDS is their limit)
-__global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames)
+// so that a batch of short utterances keeps more planners resident per CU (they are latency chains, LDS is their limit).
+// `sils_cap` / `groups_cap` (<= PLAN_LDS_SILS / PLAN_LDS_GROUPS): the run and group arrays, sized by the launcher from the
+// batch's Tmax / Smax as well.  With the fixed maxima a planner held 9.7 KB and the sixteen planners of a CU's share of a
+// 4096-utterance batch held ALL of its LDS: a K1 launch of the other head that ran beside them got no workgroup in until
+// they left (profiles/r05_stagger_timeline.txt: k_dp4_any 390 us alone, 770-880 us beside a planner).
+__global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, int sils_cap, int groups_cap)
 {
     extern __shared__ __attribute__((aligned(16))) float plan_dyn[];
     float *scs = plan_dyn; // float32(cumsum) of the vector under the sliding window (detect_silence_w)
-    __shared__ __attribute__((aligned(8))) int32_t s_aud[2 * PLAN_LDS_SILS], s_sub[2 * PLAN_LDS_SILS]; // (s_sub doubles as PLAN_LDS_SILS float64)
-    __shared__ int32_t s_groups[2 * PLAN_LDS_GROUPS], s_match[2 * PLAN_LDS_GROUPS];
-    __shared__ SegRec s_segs[2 * PLAN_LDS_GROUPS + 4];
+    float *sps = plan_dyn + lds_frames; // P(SIL) of the utterance: every pass of the planner reads it from here (round 5; until
+                                        // then each pass, the top-level one and one per piece, began with a memory round trip)
+    int32_t *s_aud = (int32_t *)(plan_dyn + 2 * lds_frames);  // [2 * sils_cap]   (8-byte aligned: lds_frames is a multiple of 64)
+    int32_t *s_sub = s_aud + 2 * sils_cap;                // [2 * sils_cap]   (doubles as sils_cap float64; sils_cap is even)
+    int32_t *s_groups = s_sub + 2 * sils_cap;             // [2 * groups_cap]
+    int32_t *s_match = s_groups + 2 * groups_cap;         // [2 * groups_cap]
+    SegRec *s_segs = (SegRec *)(s_match + 2 * groups_cap); // [2 * groups_cap + 4]
+    int32_t *s_pbk = (int32_t *)(s_segs + 2 * groups_cap + 4); // [2 * groups_cap + 4]
     const int lane = threadIdx.x & 63;
     const int n_cand = a.counters[1];
     for (int ci = blockIdx.x; ci < n_cand; ci += gridDim.x) {
@@ -456,7 +501,7 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames)
         // posteriors stay far below it; the true worst case is ~nwin / 2 overlapping runs, which overflows the scratch and
         // is reported per utterance (see plan_candidate).  SIL groups alternate with other tokens: (S + 1) / 2 at most
         const int min_k = (S > 200 && a.p.anchors > 3) ? 3 : (a.p.anchors > 0 ? a.p.anchors : 1);
-        const bool coop = T <= lds_frames && (T / min_k + 2 <= PLAN_LDS_SILS) && ((S + 1) / 2 + 1 <= PLAN_LDS_GROUPS);
+        const bool coop = T <= lds_frames && (T / min_k + 2 <= sils_cap) && ((S + 1) / 2 + 1 <= groups_cap);
         __builtin_amdgcn_wave_barrier(); // the previous candidate's readers are done
         PlanScratch sc;
         bool planned = false;
@@ -466,9 +511,14 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames)
             // the serial sum, and without a second staged vector all 16 planners of a CU's share of a 4096-utterance
             // batch are resident at once (LDS was the limit: 12 KB each at T = 1000, 2.5 rounds of ~70 us)
             sc.groups = s_groups; sc.aud = s_aud; sc.sub = s_sub; sc.match = s_match; sc.segs = s_segs;
-            sc.aud_cap = PLAN_LDS_SILS; sc.cs = scs;
+            sc.aud_cap = sils_cap; sc.cs = scs; sc.pbk = s_pbk;
+#pragma unroll 8
+            for (int i = lane; i < T; i += 64) sps[i] = ps[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             sc.gsub = gscr + 2 * (a.Smax + 2) + 2 * (a.Tmax + 2); sc.gsub_cap = a.Tmax + 2;
-            planned = plan_candidate<true>(a, b, ps, sc, lane);
+            planned = plan_candidate<true>(a, b, sps, sc, lane);
         }
         if (!planned && lane == 0) { // too large for the LDS arrays (by the admission test, or found out while planning)
             int32_t *scr = gscr;
@@ -477,7 +527,7 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames)
             sc.sub = scr; scr += 2 * (a.Tmax + 2);
             sc.match = scr; scr += 2 * (a.Smax + 2);
             sc.segs = (SegRec *)scr;
-            sc.aud_cap = a.Tmax + 2; sc.cs = nullptr; sc.gsub = nullptr; sc.gsub_cap = 0;
+            sc.aud_cap = a.Tmax + 2; sc.cs = nullptr; sc.gsub = nullptr; sc.gsub_cap = 0; sc.pbk = nullptr;
             (void)plan_candidate<false>(a, b, ps, sc, lane);
         }
     }
@@ -503,5 +553,23 @@ extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t 
     // (cutting the batch into slices so that the planner of one slice runs beside the row pass of the next was measured
     // and lost: the row pass slows down by more than the planner hides, 1.12 -> 1.17-1.23 ms per step)
     const int lds_frames = a.Tmax >= PLAN_LDS_FRAMES ? PLAN_LDS_FRAMES : ((a.Tmax + 63) / 64) * 64;
-    hipLaunchKernelGGL(k_plan_seg, dim3(a.B < 16384 ? a.B : 16384), dim3(64), lds_frames * sizeof(float), stream, a, lds_frames);
+    // the run / group arrays by the batch's shape (the admission test of the cooperative path, with Tmax / Smax for T / S)
+    const int anchors = a.p.anchors > 0 ? a.p.anchors : 1;
+    const int min_k = (a.Smax > 200 && anchors > 3) ? 3 : anchors;
+    int sils_cap = lds_frames / min_k + 2, groups_cap = (a.Smax + 1) / 2 + 1;
+    sils_cap = sils_cap > PLAN_LDS_SILS ? PLAN_LDS_SILS : ((sils_cap + 1) & ~1);
+    groups_cap = groups_cap > PLAN_LDS_GROUPS ? PLAN_LDS_GROUPS : ((groups_cap + 1) & ~1);
+    static const bool full_caps = std::getenv("BFA_PLAN_LDS_FULL") != nullptr; // (A/B: the fixed maxima of rounds 3-4)
+    if (full_caps) { sils_cap = PLAN_LDS_SILS; groups_cap = PLAN_LDS_GROUPS; }
+    if (sils_cap < 8) sils_cap = 8;
+    if (groups_cap < 4) groups_cap = 4;
+    const size_t lds = 2 * (size_t)lds_frames * sizeof(float) + (size_t)(4 * sils_cap + 4 * groups_cap + 2 * groups_cap + 4) * sizeof(int32_t) +
+                       (size_t)(2 * groups_cap + 4) * sizeof(SegRec);
+    // Eight planners per CU, not one per utterance: a resident planner is a latency chain that holds 56 vector registers
+    // and 11 KB of LDS, and sixteen of them per CU left the kernels of the other head (or of the next call) that run beside
+    // them a third of their occupancy -- realtext one call at a time 1.90 / 1.87 / 1.84 / 1.79 ms with 16 / 12 / 8 / 4 per CU
+    // on the planner of rounds 3-4; with P(SIL) staged in LDS and the batched list appends 8 per CU is as fast as 16 for
+    // one head alone and 2 % faster with three calls in flight (profiles/r05_plan_grid_ab.txt)
+    static const int plan_grid = [] { const char *e = std::getenv("BFA_PLAN_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2048; }(); // (A/B: profiles/r05_plan_grid_ab.txt)
+    hipLaunchKernelGGL(k_plan_seg, dim3(a.B < plan_grid ? a.B : plan_grid), dim3(64), lds, stream, a, lds_frames, sils_cap, groups_cap);
 }

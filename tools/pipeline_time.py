@@ -51,8 +51,10 @@ if os.environ.get("BFA_PROFILE_HOST"):
     import pstats
     pr = cProfile.Profile()
     pr.enable()
-    for _ in range(5):
-        al.extract_timestamps_from_logits(lp, lg, spec, seqs, wl, start_offset_times=0.0, as_arrays=True, fused=FUSED)
+    tg = toks if os.environ["BFA_PROFILE_HOST"] == "tensor" else seqs
+    for _ in range(20):
+        al.extract_timestamps_from_logits(lp, lg, spec, tg, wl, start_offset_times=0.0, as_arrays=True, fused=FUSED)
     torch.cuda.synchronize()
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
