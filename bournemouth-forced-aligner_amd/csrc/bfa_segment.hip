@@ -125,16 +125,83 @@ __device__ int detect_silence_w(const float *ps, int Tx, float thr, int k, int32
             {
                 const long long xb = __builtin_bit_cast(long long, (double)x); // converted once per lane, not once per step
                 const int xlo = (int)(xb & 0xffffffffll), xhi = (int)(xb >> 32);
-#define BFA_CS_FIRST(J) "v_readlane_b32 s20, %[xlo], " #J "\n\tv_readlane_b32 s21, %[xhi], " #J "\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
-#define BFA_CS_STEP(J) "v_readlane_b32 s20, %[xlo], " #J "\n\tv_readlane_b32 s21, %[xhi], " #J "\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                // (generated: tools/gen_cs_chain.py)  The broadcasts of step j + 5 are issued ahead of the add of step j, into six rotating
+                // SGPR pairs: written right before its add, a v_readlane result reached the add ~10 cycles late at every step (the
+                // planner's phase clocks, profiles/r05_plan_stamps.txt: 55 cycles per step of four instructions).  Same additions, same order.
                 asm volatile(
-                    BFA_CS_FIRST(0) BFA_CS_STEP(1) BFA_CS_STEP(2) BFA_CS_STEP(3) BFA_CS_STEP(4) BFA_CS_STEP(5) BFA_CS_STEP(6) BFA_CS_STEP(7) BFA_CS_STEP(8) BFA_CS_STEP(9) BFA_CS_STEP(10) BFA_CS_STEP(11) BFA_CS_STEP(12) BFA_CS_STEP(13) BFA_CS_STEP(14) BFA_CS_STEP(15) BFA_CS_STEP(16) BFA_CS_STEP(17) BFA_CS_STEP(18) BFA_CS_STEP(19) BFA_CS_STEP(20) BFA_CS_STEP(21) BFA_CS_STEP(22) BFA_CS_STEP(23) BFA_CS_STEP(24) BFA_CS_STEP(25) BFA_CS_STEP(26) BFA_CS_STEP(27) BFA_CS_STEP(28) BFA_CS_STEP(29) BFA_CS_STEP(30) BFA_CS_STEP(31) BFA_CS_STEP(32) BFA_CS_STEP(33) BFA_CS_STEP(34) BFA_CS_STEP(35) BFA_CS_STEP(36) BFA_CS_STEP(37) BFA_CS_STEP(38) BFA_CS_STEP(39) BFA_CS_STEP(40) BFA_CS_STEP(41) BFA_CS_STEP(42) BFA_CS_STEP(43) BFA_CS_STEP(44) BFA_CS_STEP(45) BFA_CS_STEP(46) BFA_CS_STEP(47) BFA_CS_STEP(48) BFA_CS_STEP(49) BFA_CS_STEP(50) BFA_CS_STEP(51) BFA_CS_STEP(52) BFA_CS_STEP(53) BFA_CS_STEP(54) BFA_CS_STEP(55) BFA_CS_STEP(56) BFA_CS_STEP(57) BFA_CS_STEP(58) BFA_CS_STEP(59) BFA_CS_STEP(60) BFA_CS_STEP(61) BFA_CS_STEP(62) BFA_CS_STEP(63)
+                    "v_readlane_b32 s20, %[xlo], 0\n\tv_readlane_b32 s21, %[xhi], 0\n\t"
+                    "v_readlane_b32 s22, %[xlo], 1\n\tv_readlane_b32 s23, %[xhi], 1\n\t"
+                    "v_readlane_b32 s24, %[xlo], 2\n\tv_readlane_b32 s25, %[xhi], 2\n\t"
+                    "v_readlane_b32 s26, %[xlo], 3\n\tv_readlane_b32 s27, %[xhi], 3\n\t"
+                    "v_readlane_b32 s28, %[xlo], 4\n\tv_readlane_b32 s29, %[xhi], 4\n\t"
+                    "v_readlane_b32 s30, %[xlo], 5\n\tv_readlane_b32 s31, %[xhi], 5\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 6\n\tv_readlane_b32 s21, %[xhi], 6\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 7\n\tv_readlane_b32 s23, %[xhi], 7\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 8\n\tv_readlane_b32 s25, %[xhi], 8\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 9\n\tv_readlane_b32 s27, %[xhi], 9\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 10\n\tv_readlane_b32 s29, %[xhi], 10\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 11\n\tv_readlane_b32 s31, %[xhi], 11\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 12\n\tv_readlane_b32 s21, %[xhi], 12\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 13\n\tv_readlane_b32 s23, %[xhi], 13\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 14\n\tv_readlane_b32 s25, %[xhi], 14\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 15\n\tv_readlane_b32 s27, %[xhi], 15\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 16\n\tv_readlane_b32 s29, %[xhi], 16\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 17\n\tv_readlane_b32 s31, %[xhi], 17\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 18\n\tv_readlane_b32 s21, %[xhi], 18\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 19\n\tv_readlane_b32 s23, %[xhi], 19\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 20\n\tv_readlane_b32 s25, %[xhi], 20\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 21\n\tv_readlane_b32 s27, %[xhi], 21\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 22\n\tv_readlane_b32 s29, %[xhi], 22\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 23\n\tv_readlane_b32 s31, %[xhi], 23\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 24\n\tv_readlane_b32 s21, %[xhi], 24\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 25\n\tv_readlane_b32 s23, %[xhi], 25\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 26\n\tv_readlane_b32 s25, %[xhi], 26\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 27\n\tv_readlane_b32 s27, %[xhi], 27\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 28\n\tv_readlane_b32 s29, %[xhi], 28\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 29\n\tv_readlane_b32 s31, %[xhi], 29\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 30\n\tv_readlane_b32 s21, %[xhi], 30\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 31\n\tv_readlane_b32 s23, %[xhi], 31\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 32\n\tv_readlane_b32 s25, %[xhi], 32\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 33\n\tv_readlane_b32 s27, %[xhi], 33\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 34\n\tv_readlane_b32 s29, %[xhi], 34\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 35\n\tv_readlane_b32 s31, %[xhi], 35\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 36\n\tv_readlane_b32 s21, %[xhi], 36\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 37\n\tv_readlane_b32 s23, %[xhi], 37\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 38\n\tv_readlane_b32 s25, %[xhi], 38\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 39\n\tv_readlane_b32 s27, %[xhi], 39\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 40\n\tv_readlane_b32 s29, %[xhi], 40\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 41\n\tv_readlane_b32 s31, %[xhi], 41\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 42\n\tv_readlane_b32 s21, %[xhi], 42\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 43\n\tv_readlane_b32 s23, %[xhi], 43\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 44\n\tv_readlane_b32 s25, %[xhi], 44\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 45\n\tv_readlane_b32 s27, %[xhi], 45\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 46\n\tv_readlane_b32 s29, %[xhi], 46\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 47\n\tv_readlane_b32 s31, %[xhi], 47\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 48\n\tv_readlane_b32 s21, %[xhi], 48\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 49\n\tv_readlane_b32 s23, %[xhi], 49\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 50\n\tv_readlane_b32 s25, %[xhi], 50\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 51\n\tv_readlane_b32 s27, %[xhi], 51\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 52\n\tv_readlane_b32 s29, %[xhi], 52\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 53\n\tv_readlane_b32 s31, %[xhi], 53\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 54\n\tv_readlane_b32 s21, %[xhi], 54\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 55\n\tv_readlane_b32 s23, %[xhi], 55\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 56\n\tv_readlane_b32 s25, %[xhi], 56\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 57\n\tv_readlane_b32 s27, %[xhi], 57\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "v_readlane_b32 s28, %[xlo], 58\n\tv_readlane_b32 s29, %[xhi], 58\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "v_readlane_b32 s30, %[xlo], 59\n\tv_readlane_b32 s31, %[xhi], 59\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "v_readlane_b32 s20, %[xlo], 60\n\tv_readlane_b32 s21, %[xhi], 60\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "v_readlane_b32 s22, %[xlo], 61\n\tv_readlane_b32 s23, %[xhi], 61\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "v_readlane_b32 s24, %[xlo], 62\n\tv_readlane_b32 s25, %[xhi], 62\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
+                    "v_readlane_b32 s26, %[xlo], 63\n\tv_readlane_b32 s27, %[xhi], 63\n\ts_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[28:29]\n\t"
+                    "s_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[30:31]\n\t"
+                    "s_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[20:21]\n\t"
+                    "s_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[22:23]\n\t"
+                    "s_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[24:25]\n\t"
+                    "s_lshl_b64 exec, exec, 1\n\tv_add_f64 %[acc], %[acc], s[26:27]\n\t"
                     "s_mov_b64 exec, -1"
                     : [acc] "+v"(acc)
                     : [xlo] "v"(xlo), [xhi] "v"(xhi)
-                    : "scc", "s20", "s21");
-#undef BFA_CS_FIRST
-#undef BFA_CS_STEP
+                    : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
             }
 #endif
             if (base + lane < Tx) cs[base + lane] = (float)acc;
@@ -211,6 +278,13 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
     };
     const DevParams &p = a.p;
     const int T = a.uT[b], S = a.uS[b];
+#ifdef BFA_PLAN_STAMPS // (measurement builds, tools/plan_stamps.py: s_memrealtime at the phase boundaries, in the utterance's global scratch)
+    unsigned long long *const gst = reinterpret_cast<unsigned long long *>(a.seg_scratch + (int64_t)b * a.seg_scratch_per_utt) + 1;
+    auto stamp = [&](int k) { if (COOP && lane == 0) gst[k] = __builtin_amdgcn_s_memrealtime(); };
+#else
+    auto stamp = [&](int) {};
+#endif
+    stamp(1);
     const int32_t *tok = a.tokens + (int64_t)b * a.Smax;
     const int fallback_mode = -1 - a.umode[b];
     int32_t *groups = sc.groups, *aud = sc.aud, *sub = sc.sub, *match = sc.match;
@@ -246,6 +320,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         }
     }
     if (ng == 0) ok = false; // :293-295
+    stamp(2);
     int mf = p.anchors, na = 0;
     if (ok) { // :296-308
         na = silences(ps, T, 0.9f, mf, aud, aud_cap);
@@ -266,6 +341,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         }
         if (na <= 0) ok = false; // :315-320
     }
+    stamp(3);
     // ---- _match_silences :226-266
     int nm = 0;
     if (ok) {
@@ -340,6 +416,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         }
         if (npieces == 0) ok = false; // :454-455
     }
+    stamp(4);
     if (!ok) { // keep the standard-mode fallback item -- which may be the "audio too short" error (:161-165)
         if (writer) {
             if (fallback_mode == BFA_FALLBACK_TOO_SHORT) { a.status[b] = BFA_ITEM_TOO_SHORT; a.umode[b] = BFA_MODE_EMPTY; }
@@ -357,6 +434,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         if (writer) { a.status[b] = BFA_ITEM_TOO_LARGE; a.items[b].kind = ITEM_FILL_BLANK; a.umode[b] = BFA_MODE_SEGMENTED; }
         return true;
     }
+    stamp(5);
     // ---- emit one item per piece (:377-451)
     int64_t bp_off = (int64_t)b * a.bp_per_utt;
     int anch_used = 0;
@@ -430,6 +508,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         }
         ++slot;
     }
+    stamp(6);
     if (COOP) {
         const int nemit = slot - base; // (<= 2 * groups_cap + 1 entries of pbk)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -463,6 +542,10 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
         a.items[b].kind = ITEM_NONE; // the standard-mode fallback item is not needed
         a.umode[b] = BFA_MODE_SEGMENTED;
     }
+    stamp(7);
+#ifdef BFA_PLAN_STAMPS
+    if (COOP && lane == 0) { gst[8] = ((unsigned long long)(unsigned)npieces << 32) | (unsigned)na; gst[9] = ((unsigned long long)(unsigned)blockIdx.x << 32) | (unsigned)T; gst[-1] = 0x5a5a1234c3c3abcdull; gst[10] = 0x3c3c4321a5a5dcbaull; }
+#endif
     return true;
 }
 
@@ -492,6 +575,8 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, in
     SegRec *s_segs = (SegRec *)(s_match + 2 * groups_cap); // [2 * groups_cap + 4]
     int32_t *s_pbk = (int32_t *)(s_segs + 2 * groups_cap + 4); // [2 * groups_cap + 4]
     const int lane = threadIdx.x & 63;
+    // (wave priority 2 / 3 -- the DP consumers that run beside a planner are at 3 -- measured: real text one call at a time
+    // 1.709 -> 1.744 / 1.741 ms, profiles/r05_plan_prio_ab.txt)
     const int n_cand = a.counters[1];
     for (int ci = blockIdx.x; ci < n_cand; ci += gridDim.x) {
         const int b = a.cand[ci];
@@ -511,6 +596,9 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, in
             // the serial sum, and without a second staged vector all 16 planners of a CU's share of a 4096-utterance
             // batch are resident at once (LDS was the limit: 12 KB each at T = 1000, 2.5 rounds of ~70 us)
             sc.groups = s_groups; sc.aud = s_aud; sc.sub = s_sub; sc.match = s_match; sc.segs = s_segs;
+#ifdef BFA_PLAN_STAMPS
+            if (lane == 0) (reinterpret_cast<unsigned long long *>(gscr) + 1)[0] = __builtin_amdgcn_s_memrealtime();
+#endif
             sc.aud_cap = sils_cap; sc.cs = scs; sc.pbk = s_pbk;
 #pragma unroll 8
             for (int i = lane; i < T; i += 64) sps[i] = ps[i];
