@@ -1,31 +1,18 @@
-# tools/r5_stagger_ab.sh -- the planner's LDS footprint (BFA_PLAN_LDS_FULL = rounds 3-4), its grid (BFA_PLAN_GRID) and staggered
-# heads (BFA_STAGGER_HEADS = 0 / 1 / 2) on the real-text step, interleaved on one box
+# tools/r5_stagger_ab.sh -- staggered heads (BFA_STAGGER_HEADS = 0 / 1) x planner wave priority (0: build, 3: variant), one box
 cd $GRAFT_REPO_ROOT
 last() { grep "^{" | tail -1; }
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -x -q -m gpu -k "segment or sil or level2 or realtext or golden or pipeline or planner" 2>&1 | tail -2
-run() { # name, env...
-  name=$1; shift
+V=$PWD/bournemouth-forced-aligner_amd/variants/libbfa_plan_prio3.so
+run() { name=$1; shift
   env "$@" python bench.py --config realtext --steps 20 --warmup 5 --inflight 1 --parity-sample 128 2>/dev/null | last | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$name realtext inflight1 %.4f ms' % d['ms_per_step'], d['parity']['mismatching_utterances'])"
 }
 for rep in 1 2 3; do
-  run "full-lds stagger=0" BFA_PLAN_LDS_FULL=1 BFA_STAGGER_HEADS=0
-  run "small-lds stagger=0" BFA_STAGGER_HEADS=0
-  run "small-lds stagger=1" BFA_STAGGER_HEADS=1
-  run "small-lds stagger=2" BFA_STAGGER_HEADS=2
-  run "small-lds stagger=0 grid2048" BFA_STAGGER_HEADS=0 BFA_PLAN_GRID=2048
-  run "small-lds stagger=1 grid2048" BFA_STAGGER_HEADS=1 BFA_PLAN_GRID=2048
+  run "stagger=0 prio0" BFA_STAGGER_HEADS=0
+  run "stagger=1 prio0" BFA_STAGGER_HEADS=1
+  run "stagger=0 prio3" BFA_STAGGER_HEADS=0 BFA_HIP_LIBRARY=$V
+  run "stagger=1 prio3" BFA_STAGGER_HEADS=1 BFA_HIP_LIBRARY=$V
+  run "stagger=2 prio3" BFA_STAGGER_HEADS=2 BFA_HIP_LIBRARY=$V
 done
-for rep in 1 2; do
-  for v in full small; do
-    if [ $v = full ]; then export BFA_PLAN_LDS_FULL=1; else unset BFA_PLAN_LDS_FULL; fi
-    python bench.py --config realtext --steps 20 --warmup 5 --parity-sample 0 2>/dev/null | last | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v-lds realtext 3 in flight %.4f ms' % d['ms_per_step'])"
-    python tests/sil_time.py 2>/dev/null | last | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v-lds sil %.4f ms' % d['ms_per_step'])"
-  done
-done
-unset BFA_PLAN_LDS_FULL
-for sg in 0 1; do
-  export BFA_STAGGER_HEADS=$sg
-  echo "== small-lds stagger=$sg"
-  bash tools/timeline.sh r5sg$sg 2 python $PWD/bench.py --config realtext --steps 5 --warmup 2 --settle-ms 0 --min-timed-steps 5 --parity-sample 0 --inflight 1 2>&1 | grep -v "^W2026"
-done > gpurun_out/r5_stagger_timeline2.txt 2>&1
-grep "last step\|==" gpurun_out/r5_stagger_timeline2.txt
+export BFA_STAGGER_HEADS=1 BFA_HIP_LIBRARY=$V
+echo "== stagger=1 prio3"
+bash tools/timeline.sh r5sg1p3 2 python $PWD/bench.py --config realtext --steps 5 --warmup 2 --settle-ms 0 --min-timed-steps 5 --parity-sample 0 --inflight 1 2>&1 | grep -v "^W2026" > gpurun_out/r5_stagger_timeline4.txt 2>&1
+grep -v "rocprofv3\|amdgpu.ids" gpurun_out/r5_stagger_timeline4.txt
