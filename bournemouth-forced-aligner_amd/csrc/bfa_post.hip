@@ -3,7 +3,6 @@
 // and extend_soft_boundaries_func (core.py:682-809).  One wavefront per utterance, one lane per
 // tuple; each of the four extension passes only reads neighbour fields that the same pass does not
 // write, so a pass is data-parallel and passes are separated by a wave-level LDS sync.
-#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "bfa_math.hpp"
@@ -552,8 +551,7 @@ extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t 
         (void)hipFuncSetAttribute((const void *)k_postconf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)k_postconf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    static const int post_grid = [] { const char *e = std::getenv("BFA_POST_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 65536; }(); // (A/B)
-    const int grid = B < post_grid ? B : post_grid;
+    const int grid = B < 65536 ? B : 65536; // (fewer workgroups were measured: profiles/r05_postconf_clip_grid_ab.txt)
     if (row_stats) hipLaunchKernelGGL(k_postconf<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL(k_postconf<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();

@@ -11,7 +11,6 @@
 //
 // All control-flow arithmetic is the reference's: python floats are doubles, int() truncates,
 // torch.cumsum(float32) is a float64 running sum rounded to float32 at every element.
-#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "bfa_softmax.hpp"
@@ -552,6 +551,9 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
 // one wavefront per candidate, planning with LDS scratch (the planner walks its run / group / segment arrays several
 // times with serial, dependent accesses -- from global memory that latency was the whole kernel time).  Utterances whose
 // worst-case counts exceed the LDS arrays use the global scratch instead.
+#ifndef BFA_PLAN_WGS
+#define BFA_PLAN_WGS 2048 // workgroups of k_plan_seg = eight per CU (compile-time A/B knob; profiles/r05_plan_grid_ab.txt)
+#endif
 constexpr int PLAN_LDS_FRAMES = 2048;
 constexpr int PLAN_LDS_SILS = 128;  // audio silences / sub-silences (pairs)
 constexpr int PLAN_LDS_GROUPS = 64; // target SIL groups / matches (pairs)
@@ -647,8 +649,6 @@ extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t 
     int sils_cap = lds_frames / min_k + 2, groups_cap = (a.Smax + 1) / 2 + 1;
     sils_cap = sils_cap > PLAN_LDS_SILS ? PLAN_LDS_SILS : ((sils_cap + 1) & ~1);
     groups_cap = groups_cap > PLAN_LDS_GROUPS ? PLAN_LDS_GROUPS : ((groups_cap + 1) & ~1);
-    static const bool full_caps = std::getenv("BFA_PLAN_LDS_FULL") != nullptr; // (A/B: the fixed maxima of rounds 3-4)
-    if (full_caps) { sils_cap = PLAN_LDS_SILS; groups_cap = PLAN_LDS_GROUPS; }
     if (sils_cap < 8) sils_cap = 8;
     if (groups_cap < 4) groups_cap = 4;
     const size_t lds = 2 * (size_t)lds_frames * sizeof(float) + (size_t)(4 * sils_cap + 4 * groups_cap + 2 * groups_cap + 4) * sizeof(int32_t) +
@@ -658,6 +658,6 @@ extern "C" void bfa_launch_segment_plan(const bfa::AlignArgs *args, hipStream_t 
     // them a third of their occupancy -- realtext one call at a time 1.90 / 1.87 / 1.84 / 1.79 ms with 16 / 12 / 8 / 4 per CU
     // on the planner of rounds 3-4; with P(SIL) staged in LDS and the batched list appends 8 per CU is as fast as 16 for
     // one head alone and 2 % faster with three calls in flight (profiles/r05_plan_grid_ab.txt)
-    static const int plan_grid = [] { const char *e = std::getenv("BFA_PLAN_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2048; }(); // (A/B: profiles/r05_plan_grid_ab.txt)
+    constexpr int plan_grid = BFA_PLAN_WGS;
     hipLaunchKernelGGL(k_plan_seg, dim3(a.B < plan_grid ? a.B : plan_grid), dim3(64), lds, stream, a, lds_frames, sils_cap, groups_cap);
 }

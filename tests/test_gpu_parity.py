@@ -398,6 +398,27 @@ def test_segmented_mode_parity(ora, gpu_device, anchors):
     assert (md == 2).sum() >= 1
 
 
+def test_segmented_mode_more_utterances_than_planners(ora, gpu_device):
+    """k_plan_seg runs eight wavefronts per CU (2 048 workgroups), each taking several candidate utterances one after the
+    other with the same LDS arrays (P(SIL), cumulative sums, run / group / segment / bucket scratch): a call with more
+    silence-anchored candidates than planner workgroups, short utterances of mixed lengths so that the utterances a wave
+    takes in a row differ in every array's fill."""
+    rng = np.random.default_rng(977)
+    lps, toks = [], []
+    for i in range(2600):
+        T = int(rng.integers(40, 140))
+        S = int(rng.integers(3, max(4, T // 6)))
+        lp, tk, _ = cases.planted_case(rng, T, S, C=67, peak=float(rng.choice([9.0, 5.0])),
+                                       sil_rate=float(rng.choice([0.15, 0.3])), sil_len=(4, 24), repeat_rate=0.05)
+        lps.append(lp)
+        toks.append(tk)
+    lp, tk, T_len, S_len = cases.pad_batch(lps, toks, 67, 66)
+    res, exp = _run_both(ora, gpu_device, lp, tk, T_len, S_len, 67, anchors=5, tf=True)
+    _compare(res, exp, T_len)
+    md = res.mode.cpu().numpy()
+    assert (md == 1).sum() >= 1500, "test inputs did not exercise the segmented mode"
+
+
 def test_segmented_mode_group_head_and_flags(ora, gpu_device):
     rng = np.random.default_rng(41)
     lps, toks = [], []
