@@ -26,7 +26,7 @@ EXPORTS = ["bfa_version", "bfa_abi_version", "bfa_create", "bfa_destroy", "bfa_l
            "bfa_postprocess", "bfa_log_softmax", "bfa_profile_enable", "bfa_profile_collect",
            "bfa_prepare_emissions", "bfa_stitch_windows", "bfa_align_heads", "bfa_profile_collect_spans", "bfa_set_option",
            "bfa_pack_words", "bfa_pack_results", "bfa_index_records", "bfa_call_path", "bfa_profile_copy",
-           "bfa_pack16_words", "bfa_pack_results16"]
+           "bfa_pack16_words", "bfa_pack_results16", "bfa_call_counters"]
 
 
 class BfaParams(ctypes.Structure):
@@ -107,6 +107,7 @@ def lib():
     L.bfa_pack16_words.argtypes = [i32, i64]
     L.bfa_pack16_words.restype = i64
     L.bfa_pack_results16.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    L.bfa_call_counters.argtypes = [vp, vp, i32, i32, i32, i32, ctypes.POINTER(BfaParams), ctypes.POINTER(ctypes.c_int32), vp]
     L.bfa_index_records.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L

@@ -10,6 +10,7 @@ this package: they are injected as callables and stay on PyTorch-ROCm / the host
     phonemizer(text)             -> dict(ph66=[ids], pg16=[group ids] (optional), words/word_num/eipa (optional))
 """
 import itertools
+import threading
 
 import numpy as np
 import torch
@@ -23,7 +24,7 @@ _ROW8 = np.dtype([("id", "<i4"), ("start", "<i4"), ("end", "<i4"), ("idx", "<i4"
                   ("start_ms", "<f4"), ("end_ms", "<f4")])
 
 
-_STAGE = {}  # (device, slot) -> pinned uint8 block, grow-only: the staging area of _to_host
+_STAGE = threading.local()  # per host thread: {device -> pinned uint8 block, grow-only}, the staging area of _to_host
 
 
 def _to_host(*tensors):
@@ -36,10 +37,12 @@ def _to_host(*tensors):
         return [t.numpy() for t in tensors]
     sizes = [(t.numel() * t.element_size() + 255) & ~255 for t in tensors]
     total = sum(sizes)
-    key = (dev.index, "host")
-    blk = _STAGE.get(key)
+    # one block per host thread and device: the GIL is released while the copies and the synchronisation run, so two threads
+    # (an aligner / handle slot each) must not stage through the same bytes
+    blocks = _STAGE.__dict__.setdefault("blocks", {})
+    blk = blocks.get(dev.index)
     if blk is None or blk.numel() < total:
-        blk = _STAGE[key] = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        blk = blocks[dev.index] = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
     views, off = [], 0
     for t, sz in zip(tensors, sizes):
         tc = t.contiguous()

@@ -331,6 +331,23 @@ size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p
     return carve_all(c, B, Tmax, Smax, C, p, l, nullptr, true) + 256;
 }
 
+int bfa_call_counters(bfa_handle h, const void *workspace, int B, int Tmax, int Smax, int C, const bfa_params *p,
+                      int32_t *out_host, void *stream)
+{
+    if (!h || !workspace || !p || !out_host || B <= 0 || Tmax <= 0 || Smax <= 0) return BFA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(h);
+    const Layout l = layout_for(B, Tmax, Smax, p);
+    const uintptr_t aligned = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    Carve c((void *)aligned);
+    bfa::AlignArgs a;
+    std::memset(&a, 0, sizeof(a));
+    (void)carve_all(c, B, Tmax, Smax, C, p, l, &a, false);
+    if (hipMemcpyAsync(out_host, a.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return fail(h, BFA_ERR_LAUNCH, "copy of the call counters failed");
+    return BFA_OK;
+}
+
 } // extern "C"
 
 static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,

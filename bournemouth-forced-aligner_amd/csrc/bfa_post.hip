@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
         if (a.do_conf) {
             // ---- _calculate_confidences (utils.py:70-113) on the tuples as they are now
             float *cf = a.conf + (int64_t)b * a.seg_cap;
-            for (int i = m + lane; i < a.seg_cap; i += 64) cf[i] = 0.0f; // the caller's buffer needs no fill ahead of the call
+            for (int i = (m < 0 ? 0 : m) + lane; i < a.seg_cap; i += 64) cf[i] = 0.0f; // the caller's buffer needs no fill ahead of the call
             int bad = 0;
             // does any tuple read a cell that an earlier tuple has written through its 0-dim view?
             int alias = 0;

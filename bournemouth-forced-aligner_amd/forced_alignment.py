@@ -254,6 +254,21 @@ class AlignmentResult:
                 raise RuntimeError(f"item {b}: the class_mask hint excludes what this utterance needs (a K1 class bit is "
                                    f"missing, or no-silence was promised although the target contains the silence id)")
 
+    def call_counters(self):
+        """Diagnostics (bfa_call_counters; synchronises): what the items of the call that produced this result did --
+        {"items", "routed_exact", "redone_full", "redone_exact"}.  Only valid until the decoder's next call (the counters
+        live in its workspace)."""
+        B, Tmax, Smax, C, params, ws, dev = self._call
+        L = _lib.lib()
+        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+        out = (ctypes.c_int32 * 16)()
+        with torch.cuda.device(dev):
+            rc = L.bfa_call_counters(h, ws.data_ptr(), B, Tmax, Smax, C, ctypes.byref(params), out,
+                                     torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, h, "bfa_call_counters")
+        return {"items": int(out[0]), "routed_exact": int(out[1]), "redone_full": int(out[2]), "redone_exact": int(out[3]),
+                "raw": [int(v) for v in out]}
+
     def to_lists(self, check_status=False):
         """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871).
         ONE kernel packs the valid rows back to back (bfa_pack_results), ONE pinned copy brings the record to the host, one
@@ -265,6 +280,7 @@ class AlignmentResult:
         bound = n * cap
         # frame counts, ids and target indices that fit 16 bits (any real batch): 8 bytes per tuple instead of 16 -- the copy
         # of the tuples is most of what the call costs the host beyond the device step (2.6 MB for the headline batch)
+        # (phoneme ids are < C <= 128: the library refuses wider posteriors, bfa_capi.cpp align_impl)
         small = self.frame_phonemes.shape[1] < 65536 and cap < 32768
         if small:
             L = _lib.lib()
@@ -296,12 +312,16 @@ class AlignmentResult:
                 self.raise_for_status()
             head = host.numpy()
             total = int(head[1])
+            if int(head[5]) != 0:   # header word 5: the record was cut (bfa.h, bfa_pack_results)
+                raise RuntimeError("bfa_pack_results: the packed record overflowed its bound")
             packed = head[lay["tuples"]:lay["tuples"] + tw * total]
         else:                               # the count table first, then exactly the packed tuples
             head = rec[:lay["tuples"]].cpu().numpy()
             if status_h is not None and bool((status_h != 0).any()):
                 self.raise_for_status()
             total = int(head[1])
+            if int(head[5]) != 0:
+                raise RuntimeError("bfa_pack_results: the packed record overflowed its bound")
             host = torch.empty((tw * total,), dtype=torch.int32, pin_memory=True)
             host.copy_(rec[lay["tuples"]:lay["tuples"] + tw * total], non_blocking=True)
             st.synchronize()
@@ -518,8 +538,13 @@ class ViterbiDecoder:
         off (the call then never touches the host)."""
         import weakref
         ts = [t for t in (pred_lens, true_seqs_lens, true_seqs) if isinstance(t, torch.Tensor)]
-        key = tuple((id(t), t._version, t.data_ptr()) for t in ts) + tuple(sorted(hint_kw.items())) + (B, Tmax, sil)
-        hit = self._dev_hint.get(key)
+        # Everything hint_and_path keys on that is not a tensor rides in the key (a decoder whose anchors / floor / window
+        # limits change must not replay the old class bits).  Targets that are NOT a tensor (host list / ndarray) are not
+        # identified by anything in the key: such a call is never served from the cache (its has_sil is recomputed below).
+        cacheable = isinstance(true_seqs, torch.Tensor)
+        key = tuple((id(t), t._version, t.data_ptr()) for t in ts) + tuple(sorted(hint_kw.items())) + \
+            (B, Tmax, sil, self.silence_anchors, self.min_phoneme_prob, self.window_max_tokens, self.window_max_frames)
+        hit = self._dev_hint.get(key) if cacheable else None
         if hit is not None and all(r() is t for r, t in zip(hit[1], ts)):
             return hit[0]
         Th = np.full(B, Tmax, np.int64) if pred_lens is None else _host_ints(pred_lens.cpu() if isinstance(pred_lens, torch.Tensor) else pred_lens)
@@ -529,10 +554,16 @@ class ViterbiDecoder:
         valid = torch.arange(toks.shape[1], device=toks.device)[None, :] < true_seqs_lens.to(toks.device)[:, None]
         has_sil = bool(((toks == sil) & valid).any())
         mask = self.hint_and_path(np.clip(Th, 0, Tmax), np.clip(Sh, 0, toks.shape[1]), has_sil, **hint_kw)[0]
-        if len(self._dev_hint) >= 8:
-            self._dev_hint.pop(next(iter(self._dev_hint)))
-        self._dev_hint[key] = (mask, [weakref.ref(t) for t in ts])
+        if cacheable:
+            if len(self._dev_hint) >= 8:
+                self._dev_hint.pop(next(iter(self._dev_hint)))
+            self._dev_hint[key] = (mask, [weakref.ref(t) for t in ts])
         return mask
+
+    def forget_device_hints(self):
+        """Drop the hints kept for device-resident length / target tensors (a caller that rewrites such a tensor behind
+        torch's version counter -- `.data`, an external kernel -- and sees BFA_ITEM_BAD_HINT calls this and aligns again)."""
+        self._dev_hint.clear()
 
     @staticmethod
     def _uniform(T):
@@ -596,6 +627,7 @@ class ViterbiDecoder:
     def _result(c):
         res = AlignmentResult(c["segs"], c["seg_count"], c["status"], c["mode"], c["fph"], c["fidx"], c["T_len"], c["S_len"])
         res._keepalive = (c["lp"], c["toks"], c["ws"])
+        res._call = (c["B"], c["Tmax"], c["Smax"], c["C"], c["params"], c["ws"], c["dev"])
         return res
 
     def align_batch(self, log_probs, true_seqs, pred_lens, true_seqs_lens, boost_targets=True, enforce_minimum=True,

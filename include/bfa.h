@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BFA_ABI_VERSION 5 /* v5: bfa_pack_results / bfa_pack_words / bfa_index_records (packed result records); v4: bfa_set_option; v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
+#define BFA_ABI_VERSION 6 /* v6: bfa_call_counters (what a call's items did: fast windows redone, exact-first routing); v5: bfa_pack_results / bfa_pack_words / bfa_index_records (packed result records); v4: bfa_set_option; v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
 
 typedef struct bfa_context *bfa_handle;
 
@@ -147,6 +147,14 @@ void bfa_params_default(bfa_params *p, int blank_id, int silence_id);
 /* bytes of device scratch bfa_align_batch needs for these shapes (shape-only upper bound, so no
  * host knowledge of the per-utterance lengths is required) */
 size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p);
+
+/* Diagnostics of the LAST bfa_align_batch / bfa_align_heads call that used `workspace` (same shapes and params as that call):
+ * copies sixteen int32 device counters to `out_host` and waits for `stream`.  [0] work items (utterances + silence-anchored
+ * pieces); [2] sliding-window items that ended at the reference's -1000 sentinel and were redone with the full layout; [3]
+ * the same, redone with the exact window; [1] utterances the window routing sent to the exact window at once (see
+ * bfa.h BFA_OPT_WINDOW_ROUTING); [4..15] piece counts per length bucket (silence-anchored mode).  Not on any hot path. */
+int bfa_call_counters(bfa_handle h, const void *workspace, int B, int Tmax, int Smax, int C, const bfa_params *p,
+                      int32_t *out_host, void *stream);
 
 /* Which launch layout bfa_align_batch takes for these shapes and hints (host arithmetic only, no device needed):
  * 0 = one kernel per class side by side, 1 = the one-kernel mixed-length path (plus class kernels for the wide classes),

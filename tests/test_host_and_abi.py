@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= set(names)
     lib.bfa_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.bfa_version()
-    assert lib.bfa_abi_version() == 5
+    assert lib.bfa_abi_version() == 6
 
 
 def test_params_default_and_workspace_query():

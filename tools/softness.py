@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""tools/softness.py -- throughput OFF the planted peak-9 generator (the C5 proxy).
+
+Every timed workload of rounds 1-5 drew logits = N(0,1) + 9 * onehot(planted): after the reference's +5 boost of every
+target column the best path loses ~0.37 log-units per frame, so a T = 1000 utterance ends at ~-370 -- above the reference's
+finite -1000 sentinel (forced_alignment.py:23,608-682) -- and the fast sliding window's result always stands.  Real
+posteriors need not be that sharp: at -1.0 per frame a 16-s segment ends below the sentinel and the reference's own DP
+enters its sentinel regime (everything clamps to -1000 and the backpointers follow the wrapped closed form).  This tool
+sweeps the sharpness (`--peaks`) over four call shapes and reports for each setting: ms per call, frames/s, the algorithmic
+roofline fraction, the log-probability per frame of the aligned path, the share of utterances that ended at the sentinel,
+what the library's items did (bfa_call_counters: routed to the exact window at once / fast windows redone), and an oracle
+parity sample.
+
+  shapes:  headline   B x T x S uniform (default 4096 x 1000 x 40), BFA_HINT_UNIFORM_LENGTHS, standard mode
+           mixed      B utterances, T ~ U[tlo, thi], S = T // tok_div, one unsorted call (k_mix + the wide class kernels)
+           realtext   bfa_align_heads on raw logits of both heads, SIL in the targets, uniform lengths
+           c5proxy    the same with T ~ U[tlo, thi], S = T // tok_div, SIL at the punctuation rate (bench.py --config c5proxy)
+
+  python tools/softness.py --shapes headline,mixed,realtext,c5proxy --peaks 9,8,7,6,5,3 --out gpurun_out/softness.jsonl
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from tools.synth import synth_batch, synth_ragged, synth_realtext, synth_realtext_ragged  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def path_stats(vd, lp, tk, Td, Sd, res, n=64, raw_logits=False):
+    """(mean log-prob per frame of the aligned path on the PREPARED emissions, share of the sample whose path sums to <=
+    -1000) over the first n utterances (forced_alignment.py:121-129 emissions via bfa_prepare_emissions)."""
+    n = min(n, lp.shape[0])
+    x = torch.log_softmax(lp[:n], dim=-1) if raw_logits else lp[:n]
+    m = vd.prepare_emissions(x, tk[:n], Td[:n], Sd[:n])
+    fph = res.frame_phonemes[:n].long().clamp(min=0)
+    g = m.gather(2, fph.unsqueeze(-1)).squeeze(-1).double()
+    mask = torch.arange(lp.shape[1], device=lp.device)[None, :] < Td[:n, None]
+    tot = (g * mask).sum(1)
+    return float(tot.sum() / mask.sum()), float((tot <= -1000.0).double().mean())
+
+
+def time_calls(fn, steps, warmup):
+    for _ in range(warmup):
+        r = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, r
+
+
+def parity_standard(lp, tk, Tl, Sl, res, C, sample):
+    from oracle import oracle as ora
+    prm = ora.make_params(C - 1, 0)
+    gs, gc = res.segs.cpu().numpy(), res.seg_count.cpu().numpy()
+    lp_h, tk_h = lp[sample].cpu().numpy(), tk[sample].cpu().numpy()
+    exp = ora.decode_alignments(lp_h, tk_h, Tl[sample], Sl[sample], prm, seg_cap=gs.shape[1])
+    mism = 0
+    for k, b in enumerate(sample):
+        c = int(exp["seg_count"][k])
+        if gc[b] != c or not (gs[b, :c] == exp["seg"][k, :c]).all():
+            mism += 1
+    return {"utterances": int(len(sample)), "mismatching_utterances": mism}
+
+
+def parity_heads(bufs, Tl, Sl, got, sample, soft=3):
+    """the oracle's whole chain (log_softmax -> decode -> coverage -> soft boundaries -> confidences), both heads"""
+    from oracle import oracle as ora
+    mism, conf_bad, maxd = 0, 0, 0.0
+    for hi, blank in ((0, 66), (1, 16)):
+        r = got[hi]
+        gs, gc, gcf = r.segs.cpu().numpy(), r.seg_count.cpu().numpy(), r.conf.cpu().numpy()
+        prm = ora.make_params(blank, 0)
+        for b in sample:
+            T, S = int(Tl[b]), int(Sl[b])
+            x = bufs[hi][b].cpu().numpy()
+            tkb = bufs[2 + hi][b].cpu().numpy()
+            lp = ora.log_softmax_rows(x)   # every padded row: extend_soft_boundaries reads the padded matrix (core.py:700)
+            res = ora.decode_alignments(lp[None], tkb[None], [T], [S], prm)
+            rows = ora.segments_as_lists(res)[0]
+            cov = ora.ensure_target_coverage_default(rows, S)
+            ext = ora.extend_soft_boundaries(lp, cov, soft) if cov else []
+            mine = [tuple(int(v) for v in row) for row in gs[b, :gc[b]]]
+            if mine != [tuple(int(v) for v in e[:4]) for e in ext]:
+                mism += 1
+                continue
+            rc, c, _s, _e = ora.confidences(lp, ext)
+            d = float(np.abs(gcf[b, :len(ext)] - c).max()) if len(ext) else 0.0
+            maxd = max(maxd, d)
+            if rc != 0 or d > 1e-4:
+                conf_bad += 1
+    return {"utterances": int(len(sample)), "heads": 2, "mismatching_utterances": mism, "confidence_beyond_1e-4": conf_bad,
+            "max_confidence_abs_diff": maxd}
+
+
+def stratified(Tl, n):
+    order = np.argsort(Tl, kind="stable")
+    pick = order[np.linspace(0, len(Tl) - 1, n).astype(np.int64)]
+    return np.unique(np.concatenate([pick, order[-min(8, n):]]))
+
+
+def run_standard(args, shape, peak, dev):
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    C = 67
+    au = AlignmentUtils(blank_id=C - 1, silence_id=0)
+    vd = au.viterbi_decoder
+    if shape == "headline":
+        B, T, S = args.batch, args.frames, args.tokens
+        lp, tk = synth_batch(B, T, S, C, 1003, dev, peak=peak, sigma=args.sigma)
+        Tl, Sl = np.full(B, T, np.int64), np.full(B, S, np.int64)
+    else:
+        B = args.batch
+        lp, tk, T_len, S_len = synth_ragged(B, args.tlo, args.thi, C, 1004, dev, peak=peak, sigma=args.sigma, tok_div=args.tok_div)
+        Tl, Sl = T_len.numpy().astype(np.int64), S_len.numpy().astype(np.int64)
+    Td, Sd = torch.from_numpy(Tl.astype(np.int32)).to(dev), torch.from_numpy(Sl.astype(np.int32)).to(dev)
+    hint, path = vd.hint_and_path(Tl, Sl, False, n_classes=C, Smax=tk.shape[1])
+    fn = lambda: au.decode_alignments_device(lp, tk, Td, Sd, class_mask=hint)  # noqa: E731
+    ms, res = time_calls(fn, args.steps, args.warmup)
+    st = res.status.cpu().numpy()
+    cnt = res.call_counters()
+    lpf, dead = path_stats(vd, lp, tk, Td, Sd, res)
+    frames = int(Tl.sum())
+    nbytes = int(((4 * C + (4 * Sl + 1 + 3) // 4 + 8) * Tl).sum())
+    sample = stratified(Tl, args.parity)
+    return {"shape": shape, "peak": peak, "sigma": args.sigma, "B": int(B), "frames": frames, "launch_path": int(path),
+            "ms_per_call": ms, "frames_per_s": frames / (ms * 1e-3), "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "path_logp_per_frame": lpf, "sample_share_at_sentinel": dead,
+            "items": {k: cnt[k] for k in ("items", "routed_exact", "redone_full", "redone_exact")},
+            "status_ok": bool((st == 0).all()), "parity": parity_standard(lp, tk, Tl, Sl, res, C, sample)}
+
+
+def run_heads(args, shape, peak, dev):
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+    B = args.batch
+    if shape == "realtext":
+        T, S = args.frames, args.tokens
+        bufs = synth_realtext(B, T, S, 2003, dev, peak=peak, gpeak=max(1.0, peak - 2.0), sigma=args.sigma)
+        Tl, Sl = np.full(B, T, np.int64), np.full(B, S, np.int64)
+    else:
+        xs = synth_realtext_ragged(B, args.tlo, args.thi, args.tok_div, 2004, dev, peak=peak, gpeak=max(1.0, peak - 2.0), sigma=args.sigma)
+        bufs, Tl, Sl = xs[:4], xs[4].numpy().astype(np.int64), xs[5].numpy().astype(np.int64)
+    xp, xg, tp, tg = bufs
+    Td, Sd = torch.from_numpy(Tl.astype(np.int32)).to(dev), torch.from_numpy(Sl.astype(np.int32)).to(dev)
+    ap, ag = AlignmentUtils(blank_id=66, silence_id=0), AlignmentUtils(blank_id=16, silence_id=0)
+    vd = ap.viterbi_decoder
+    hints = [vd.class_mask_hint(Tl, Sl, has_sil=True, n_classes=67), vd.class_mask_hint(Tl, Sl, has_sil=True, n_classes=17)]
+
+    def fn():
+        (rp, _sp), (rg, _sg) = align_heads([ap, ag], [xp, xg], [tp, tg], Td, Sd, class_masks=hints,
+                                           post={"extend": True, "boundary_softness": 3})
+        return rp, rg
+    ms, (rp, rg) = time_calls(fn, args.steps, args.warmup)
+    ok = bool((rp.status.cpu() == 0).all() and (rg.status.cpu() == 0).all() and (rp.conf_status.cpu() == 0).all()
+              and (rg.conf_status.cpu() == 0).all())
+    modes = [r.mode.cpu().numpy() for r in (rp, rg)]
+    cnt = [r.call_counters() for r in (rp, rg)]
+    frames = int(Tl.sum())
+    nbytes = int(((4 * 67 + 4 * 17 + 4 * 67 + 2 * ((4 * Sl + 1 + 3) // 4) + 2 * 8) * Tl).sum())
+    sample = stratified(Tl, max(4, args.parity // 2))
+    return {"shape": shape, "peak": peak, "gpeak": max(1.0, peak - 2.0), "sigma": args.sigma, "B": int(B), "frames": frames,
+            "ms_per_call": ms, "frames_per_s": frames / (ms * 1e-3), "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "segmented_share": [float((m == 1).mean()) for m in modes],
+            "items": [{k: c[k] for k in ("items", "redone_full", "redone_exact")} for c in cnt],
+            "status_ok": ok, "parity": parity_heads(bufs, Tl, Sl, (rp, rg), sample)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="headline,mixed,realtext,c5proxy")
+    ap.add_argument("--peaks", default="9,8,7,6,5,3")
+    ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--tokens", type=int, default=40)
+    ap.add_argument("--tlo", type=int, default=300)
+    ap.add_argument("--thi", type=int, default=1870)
+    ap.add_argument("--tok-div", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--parity", type=int, default=48)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    out = open(args.out, "a") if args.out else None
+    for shape in args.shapes.split(","):
+        for pk in [float(v) for v in args.peaks.split(",")]:
+            rec = (run_standard if shape in ("headline", "mixed") else run_heads)(args, shape, pk, dev)
+            line = json.dumps(rec)
+            print(line, flush=True)
+            if out:
+                out.write(line + "\n")
+                out.flush()
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

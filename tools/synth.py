@@ -116,7 +116,7 @@ def input_checksum(lp, T_len):
     return (bits * valid).sum(dim=(1, 2))
 
 
-def synth_batch(B, T, S, C, seed, device, peak=9.0):
+def synth_batch(B, T, S, C, seed, device, peak=9.0, sigma=1.0):
     """Planted-path posteriors: tokens iid uniform on 1..C-2 (no SIL, no blank),
     random monotone segmentation with >= 2 frames per token, logits = N(0,1) + peak*onehot(planted),
     log_probs = log_softmax(logits).  Generated on the device with a seeded torch generator."""
@@ -138,18 +138,20 @@ def synth_batch(B, T, S, C, seed, device, peak=9.0):
     tok_idx = torch.clamp((slot - 1) // 2, 0, S - 1)
     planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
     logits = torch.randn((B, T, C), generator=g, device=device, dtype=torch.float32)
+    if sigma != 1.0:
+        logits *= sigma
     logits.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, T, 1), peak, device=device))
     lp = torch.log_softmax(logits, dim=-1)
     return lp, toks.to(torch.int32)
 
 
-def synth_ragged(B, Tlo, Thi, C, seed, device, peak=9.0):
+def synth_ragged(B, Tlo, Thi, C, seed, device, peak=9.0, sigma=1.0, tok_div=25):
     """BASELINE.json configs[3] shape: T ~ U{Tlo..Thi}, S = max(1, T // 25), padded to Thi / max S.  Every
     utterance gets its own planted path over its own T frames and S tokens (same construction as synth_batch)."""
     gc = torch.Generator(device="cpu")
     gc.manual_seed(seed)
     T_len = torch.randint(Tlo, Thi + 1, (B,), generator=gc)
-    S_len = torch.clamp(T_len // 25, min=1)
+    S_len = torch.clamp(T_len // tok_div, min=1)
     Tmax, Smax = int(T_len.max()), int(S_len.max())
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -173,6 +175,8 @@ def synth_ragged(B, Tlo, Thi, C, seed, device, peak=9.0):
     tok_idx = torch.clamp((slot - 1) // 2, 0, Smax - 1)
     planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
     logits = torch.randn((B, Tmax, C), generator=g, device=device, dtype=torch.float32)
+    if sigma != 1.0:
+        logits *= sigma
     logits.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, Tmax, 1), peak, device=device))
     lp = torch.log_softmax(logits, dim=-1)
     return lp, toks.to(torch.int32), T_len.to(torch.int32), S_len.to(torch.int32)
@@ -185,7 +189,7 @@ def group_lut(device=None):
     return lut if device is None else lut.to(device)
 
 
-def synth_realtext(B, T, S, seed, device, sil_rate=1.0 / 12, sil_len=(12, 40), peak=9.0, gpeak=7.0):
+def synth_realtext(B, T, S, seed, device, sil_rate=1.0 / 12, sil_len=(12, 40), peak=9.0, gpeak=7.0, sigma=1.0):
     """What real transcripts give the aligner (SURVEY.md section 8(d) "-sil" variant, core.py:897-922): RAW logits of both
     heads (ph66: C = 67, blank 66; groups: C = 17, blank 16), targets with SIL (id 0) at ~`sil_rate` of the positions
     (punctuation -> SIL, ph66_phonemeizer.py:185-199) and a planted silence of sil_len frames for each, >= 2 frames per
@@ -214,7 +218,62 @@ def synth_realtext(B, T, S, seed, device, sil_rate=1.0 / 12, sil_len=(12, 40), p
     planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
     lut = group_lut(device)
     logits_p = torch.randn((B, T, 67), generator=g, device=device, dtype=torch.float32)
-    logits_p.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, T, 1), peak, device=device))
     logits_g = torch.randn((B, T, 17), generator=g, device=device, dtype=torch.float32)
+    if sigma != 1.0:
+        logits_p *= sigma
+        logits_g *= sigma
+    logits_p.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, T, 1), peak, device=device))
     logits_g.scatter_add_(2, lut[planted].unsqueeze(-1), torch.full((B, T, 1), gpeak, device=device))
     return logits_p, logits_g, toks.to(torch.int32), lut[toks].to(torch.int32)
+
+
+def synth_realtext_ragged(B, Tlo, Thi, tok_div, seed, device, sil_rate=1.0 / 40, sil_len=(6, 30), peak=9.0, gpeak=7.0,
+                          sigma=1.0):
+    """The C5 proxy (BASELINE.json configs[4] without the model): what synth_realtext makes, with per-utterance lengths
+    T ~ U{Tlo..Thi} (the reference cuts audio into segments of at most 30 s = 1 870 frames, README.md:1231) and
+    S = max(1, T // tok_div) targets; SIL at `sil_rate` of the positions with a planted silence of sil_len frames each (the
+    reference's committed LJSpeech outputs: 2 SIL in 110 phonemes, 64-182 ms; examples/samples/LJSpeech/LJ001-0001.vs.json),
+    >= 2 frames per other token.  Padded to [B, Thi', *] / [B, Smax].  Returns (logits_p, logits_g, tokens, group_tokens,
+    T_len i32 cpu, S_len i32 cpu)."""
+    gc = torch.Generator(device="cpu")
+    gc.manual_seed(seed)
+    T_len = torch.randint(Tlo, Thi + 1, (B,), generator=gc)
+    S_len = torch.clamp(T_len // tok_div, min=1)
+    Tmax, Smax = int(T_len.max()), int(S_len.max())
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    blank = 66
+    Td, Sd = T_len.to(device).unsqueeze(1), S_len.to(device).unsqueeze(1)
+    toks = torch.randint(1, blank, (B, Smax), generator=g, device=device)
+    is_sil = torch.rand((B, Smax), generator=g, device=device) < sil_rate
+    toks = torch.where(is_sil, torch.zeros_like(toks), toks)
+    tokslot = torch.arange(Smax, device=device).unsqueeze(0) < Sd
+    sil_frames = torch.randint(sil_len[0], sil_len[1] + 1, (B, Smax), generator=g, device=device)
+    want = torch.where(is_sil, sil_frames, torch.full_like(sil_frames, 2)) * tokslot
+    # (an utterance whose planted silences do not fit keeps 2 frames for them as well)
+    over = want.sum(dim=1, keepdim=True) > Td
+    want = torch.where(over, 2 * tokslot.to(want.dtype), want)
+    extra = (Td - want.sum(dim=1, keepdim=True)).clamp(min=0)
+    u = torch.rand((B, 2 * Smax), generator=g, device=device)
+    cuts = torch.floor(u * (extra + 1).to(u.dtype)).to(torch.int64)
+    k = torch.arange(2 * Smax, device=device).unsqueeze(0)
+    cuts = torch.where(k < 2 * Sd, cuts, extra.expand(-1, 2 * Smax))
+    cuts, _ = torch.sort(cuts, dim=1)
+    zeros = torch.zeros((B, 1), dtype=torch.int64, device=device)
+    sizes = torch.diff(torch.cat([zeros, cuts, extra], dim=1), dim=1)
+    sizes[:, 1::2] += want
+    ends = torch.cumsum(sizes, dim=1)
+    t = torch.arange(Tmax, device=device).unsqueeze(0).expand(B, Tmax).contiguous()
+    slot = torch.searchsorted(ends, t, right=True)
+    is_tok = ((slot % 2) == 1) & (t < Td)
+    tok_idx = torch.clamp((slot - 1) // 2, 0, Smax - 1)
+    planted = torch.where(is_tok, torch.gather(toks, 1, tok_idx), torch.full_like(slot, blank))
+    lut = group_lut(device)
+    logits_p = torch.randn((B, Tmax, 67), generator=g, device=device, dtype=torch.float32)
+    logits_g = torch.randn((B, Tmax, 17), generator=g, device=device, dtype=torch.float32)
+    if sigma != 1.0:
+        logits_p *= sigma
+        logits_g *= sigma
+    logits_p.scatter_add_(2, planted.unsqueeze(-1), torch.full((B, Tmax, 1), peak, device=device))
+    logits_g.scatter_add_(2, lut[planted].unsqueeze(-1), torch.full((B, Tmax, 1), gpeak, device=device))
+    return logits_p, logits_g, toks.to(torch.int32), lut[toks].to(torch.int32), T_len.to(torch.int32), S_len.to(torch.int32)
