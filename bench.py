@@ -86,24 +86,34 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.dry = bool(args.dry_run)
+        # --oversubscribe: N ranks doing REAL GPU work on fewer GPUs than ranks (device = LOCAL_RANK % device_count) with a
+        # host-side (gloo) process group: RCCL refuses two ranks on one device.  Timing means nothing there; what it proves is
+        # partition -> synthesis -> alignment -> pack -> gather -> index -> oracle check with N > 1 ranks of real results.
+        self.over = bool(getattr(args, "oversubscribe", False)) and not self.dry
         if self.dry:
             self.dev = torch.device("cpu")
         else:
             assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU implementation of the path)"
-            assert self.local_rank < torch.cuda.device_count(), \
+            assert self.over or self.local_rank < torch.cuda.device_count(), \
                 f"rank {self.rank}: local rank {self.local_rank} but only {torch.cuda.device_count()} GPUs are visible"
-            self.dev = torch.device("cuda", self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank % torch.cuda.device_count())
             torch.cuda.set_device(self.dev)
+        self.coll_dev = torch.device("cpu") if (self.dry or self.over) else self.dev   # where collective operands live
+        self.backend, self.ranks_seen = None, None
         if self.world > 1 or need_group:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(_free_port()) if self.world == 1 else "29500")
-            if self.dry:
+            if self.dry or self.over:
                 dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             self.dist = dist
             self.world = dist.get_world_size()  # what the backend reports
+            # how many ranks the communicator itself saw: an all_reduce of ones over the group (RCCL with backend nccl)
+            ones = torch.ones(1, dtype=torch.int32, device=self.coll_dev)
+            dist.all_reduce(ones)
+            self.backend, self.ranks_seen = dist.get_backend(), int(ones.item())
         if args.gpus != self.world and self.rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the process group has {self.world} ranks; reporting {self.world}",
                   file=sys.stderr)
@@ -115,11 +125,14 @@ class Ranks:
                   "would_pin": f"cuda:{self.local_rank}", "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         else:
             pr = torch.cuda.get_device_properties(self.dev)
-            me = {"rank": self.rank, "device": f"cuda:{self.local_rank}", "local_rank": self.local_rank,
+            me = {"rank": self.rank, "device": f"cuda:{self.dev.index}", "local_rank": self.local_rank,
                   "current_device": int(torch.cuda.current_device()), "name": pr.name,
                   "gcn_arch": getattr(pr, "gcnArchName", ""), "cus": pr.multi_processor_count,
                   "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")),
                   "hbm_gb": round(pr.total_memory / 2 ** 30, 1), "pid": os.getpid()}
+            if self.over:
+                me["device"] = f"cuda:{self.dev.index}"
+                me["oversubscribed"] = True
         if self.dist is None:
             return [me]
         out = [None] * self.world
@@ -130,6 +143,12 @@ class Ranks:
         if self.dist is not None:
             self.dist.barrier()
 
+    def group_record(self):
+        """{"backend", "ranks_seen", "rccl_ranks_seen"}: what the communicator saw (all_reduce of ones at start-up)"""
+        return {"backend": self.backend, "ranks_seen": self.ranks_seen,
+                "rccl_ranks_seen": self.ranks_seen if self.backend == "nccl" else None,
+                "oversubscribed": self.over}
+
     def sync(self):
         if not self.dry:
             torch.cuda.synchronize()
@@ -137,7 +156,7 @@ class Ranks:
     def max_over_ranks(self, x):
         if self.dist is None:
             return float(x), [float(x)]
-        t = torch.tensor([x], dtype=torch.float64, device=self.dev)
+        t = torch.tensor([x], dtype=torch.float64, device=self.coll_dev)
         allt = [torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(allt, t)
         vals = [float(v.item()) for v in allt]
@@ -291,7 +310,7 @@ def headline_main(args, rk):
     aus = bif.decoders
     au = aus[0]
     lib = _lib.lib()
-    hs = [_lib.handle(rk.local_rank, k) for k in range(len(aus))]
+    hs = [_lib.handle(rk.dev.index, k) for k in range(len(aus))]
     # the lengths are known on the host (constant here), and the synthetic targets never contain SIL:
     # tell the library which K1 register class occurs so that it does not launch the empty ones
     hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False, n_classes=(None if args.no_window else C))
@@ -440,6 +459,7 @@ def headline_main(args, rk):
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
             gs, gc, _gf = out.to_padded(res.segs.shape[1])
+            gs, gc = gs.to(dev), gc.to(dev)   # (host records under --oversubscribe)
             k = torch.arange(res.segs.shape[1], device=dev)[None, :] < res.seg_count[:, None]
             assert gs.shape[0] == world * B and torch.equal(gs[:B][k], res.segs[k]) \
                 and torch.equal(gc[:B], res.seg_count), "gathered records differ from rank 0's own results"
@@ -549,6 +569,7 @@ def headline_main(args, rk):
                                 "ms_per_step": only_ms, "value": world * frames_per_step / (only_ms * 1e-3)} if only_ms else None),
             "confidence_pass_ms": conf_ms,
             "gather_ms": gather_ms,
+            "rccl_ranks_seen": rk.group_record()["rccl_ranks_seen"], "group": rk.group_record(),
             "ranks": ranks,
         }
         print(json.dumps(line))
@@ -687,7 +708,7 @@ def c4_main(args, rk):
     vd.window_max_frames = args.win_frames or None   # (A/B: how long an utterance may be for K1 to try its sliding window)
     vd.window_max_tokens = args.win_tokens or None
     lib = _lib.lib()
-    h = _lib.handle(rk.local_rank)
+    h = _lib.handle(rk.dev.index)
 
     # ---- synthesis: each rank makes only its own utterances (sub-batches of <= 512 to bound the temporaries)
     t_s0 = time.perf_counter()
@@ -852,6 +873,7 @@ def c4_main(args, rk):
                          "kernel_ms": k1_step_ms, "algorithmic_bytes_per_step": total_bytes,
                          "rank0_frames": my_frames, "rank0_algorithmic_bytes": my_bytes},
             "parity_sample": parity,
+            "rccl_ranks_seen": rk.group_record()["rccl_ranks_seen"], "group": rk.group_record(),
             "ranks": ranks,
         }
         print(json.dumps(line))
@@ -920,7 +942,7 @@ def realtext_main(args, rk):
         ap.viterbi_decoder.handle_slot = ag.viterbi_decoder.handle_slot = k
         slots.append((ap, ag))
         # one call at a time: the heads of a call on two library streams; several in flight: head 1 on the side stream (bfa.h)
-        _lib.set_calls_in_flight(rk.local_rank, k, nfl > 1)
+        _lib.set_calls_in_flight(rk.dev.index, k, nfl > 1)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)] if nfl > 1 else [None]
     vd = slots[0][0].viterbi_decoder
     hints = [vd.class_mask_hint([T] * B, [S] * B, has_sil=True, n_classes=67),
@@ -1182,6 +1204,10 @@ def main():
     ap.add_argument("--parity-sample", type=int, default=None,
                     help="utterances rank 0 checks against the oracle (c4: default 256, stratified; realtext: default 512)")
     ap.add_argument("--dry-run", action="store_true", help="launch + partition + gather plumbing on gloo, no GPU work")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="N ranks with REAL GPU work on fewer GPUs than ranks (device = LOCAL_RANK %% device_count) over a gloo "
+                         "group with the records staged through pinned host memory: correctness of the N > 1 path on one GPU "
+                         "(timings are meaningless there)")
     ap.add_argument("--force-group", action="store_true",
                     help="initialise the process group even at world size 1 (exercises the N > 1 code path of the headline mode)")
     args = ap.parse_args()

@@ -15,7 +15,7 @@
 #include "bfa_types.hpp"
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void *fork_event, int naux);
+                                void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
@@ -63,6 +63,10 @@ struct bfa_context {
     hipStream_t pair[2] = {nullptr, nullptr};
     hipEvent_t pair_join[2] = {nullptr, nullptr};
     int calls_in_flight = 0; // BFA_OPT_CALLS_IN_FLIGHT
+    // The streams above are created when a call first needs them (ensure_aux / ensure_head_streams): a process that only
+    // ever aligns single-class batches -- the reference's 16-utterance chunks -- never pays for nine streams and their events
+    // (bfa_create 22 ms -> see profiles/r06_cold_start.json).
+    bool aux_tried = false, heads_tried = false;
 };
 
 namespace {
@@ -183,6 +187,55 @@ int fail(bfa_handle h, int code, const char *msg)
     return code;
 }
 
+// Auxiliary streams of a handle, created when a call first has more than one K1 kernel to run side by side (best effort:
+// without them the class kernels simply run one after the other).  The handle's device is current (DeviceGuard).
+int ensure_aux(void *ctx)
+{
+    bfa_context *h = (bfa_context *)ctx;
+    if (h->aux_tried) return h->forked ? h->naux : 0;
+    h->aux_tried = true;
+    bool ok = hipEventCreateWithFlags(&h->forked, hipEventDisableTiming) == hipSuccess;
+    if (!ok) h->forked = nullptr;
+    for (int k = 0; ok && k < bfa_context::NAUX; ++k) {
+        ok = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&h->aux_done[k], hipEventDisableTiming) == hipSuccess;
+        if (ok) h->naux = k + 1;
+    }
+    return h->forked ? h->naux : 0;
+}
+
+// Streams of bfa_align_heads, created by its first call with more than one head.
+void ensure_head_streams(bfa_context *h)
+{
+    if (h->heads_tried) return;
+    h->heads_tried = true;
+    // pair[]: two streams of the caller's (normal) priority created one right after the other, so that the runtime's
+    // round-robin puts them on two DIFFERENT hardware queues whatever their number (four by default)
+#ifndef BFA_NO_PAIR_STREAMS // (A/B of the stream -> queue mapping with several calls in flight)
+    if (hipStreamCreateWithFlags(&h->pair[0], hipStreamNonBlocking) != hipSuccess) h->pair[0] = nullptr;
+#endif
+    if (h->pair[0] && hipStreamCreateWithFlags(&h->pair[1], hipStreamNonBlocking) != hipSuccess) h->pair[1] = nullptr;
+    for (int k = 0; k < 2; ++k)
+        if (h->pair[k] && hipEventCreateWithFlags(&h->pair_join[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(h->pair[k]);
+            h->pair[k] = nullptr;
+        }
+    // The runtime maps the streams of one priority onto a few hardware queues (four by default), and a queue runs its
+    // kernels in order: created like the auxiliary streams, this stream landed on the CALLER's queue and the heads
+    // ran one behind the other (profiles/r03_realtext_timeline_before.txt).  A stream of another priority gets a queue
+    // of its own; the later heads are the narrow ones (group head: C = 17), which fill in beside the phoneme head.
+    // Lowest priority (measured against normal / high: 2.37 vs 2.42 / 2.40 ms one step in flight).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // (numerically: lowest priority = largest value)
+    if (hipStreamCreateWithPriority(&h->head_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) h->head_stream = nullptr;
+    if (hipEventCreateWithFlags(&h->head_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->head_join, hipEventDisableTiming) != hipSuccess) {
+        if (h->head_stream) (void)hipStreamDestroy(h->head_stream);
+        h->head_stream = nullptr;
+        if (h->head_fork) { (void)hipEventDestroy(h->head_fork); h->head_fork = nullptr; }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -214,48 +267,12 @@ int bfa_create(bfa_handle *out, int device)
         if (hipGetDevice(&device) != hipSuccess) return BFA_ERR_NO_DEVICE;
     }
     if (device >= n) return BFA_ERR_INVALID_ARGUMENT;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BFA_ERR_NO_DEVICE;
+    int num_cu = 0; // (one attribute, not hipGetDeviceProperties: that call fills ~1 KB of fields through dozens of queries)
+    if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return BFA_ERR_NO_DEVICE;
     bfa_context *h = new (std::nothrow) bfa_context();
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     h->device = device;
-    h->num_cu = prop.multiProcessorCount;
-    {   // auxiliary streams (best effort: without them the class kernels simply run one after the other)
-        int prev = 0;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(device);
-        // (first: consecutive in the runtime's stream -> queue round-robin)
-#ifndef BFA_NO_PAIR_STREAMS // (A/B of the stream -> queue mapping with several calls in flight)
-        if (hipStreamCreateWithFlags(&h->pair[0], hipStreamNonBlocking) != hipSuccess) h->pair[0] = nullptr;
-#endif
-        if (h->pair[0] && hipStreamCreateWithFlags(&h->pair[1], hipStreamNonBlocking) != hipSuccess) h->pair[1] = nullptr;
-        for (int k = 0; k < 2; ++k)
-            if (h->pair[k] && hipEventCreateWithFlags(&h->pair_join[k], hipEventDisableTiming) != hipSuccess) {
-                (void)hipStreamDestroy(h->pair[k]);
-                h->pair[k] = nullptr;
-            }
-        bool ok = hipEventCreateWithFlags(&h->forked, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; ok && k < bfa_context::NAUX; ++k) {
-            ok = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&h->aux_done[k], hipEventDisableTiming) == hipSuccess;
-            if (ok) h->naux = k + 1;
-        }
-        // The runtime maps the streams of one priority onto a few hardware queues (four by default), and a queue runs its
-        // kernels in order: created like the auxiliary streams, this stream landed on the CALLER's queue and the heads
-        // ran one behind the other (profiles/r03_realtext_timeline_before.txt).  A stream of another priority gets a queue
-        // of its own; the later heads are the narrow ones (group head: C = 17), which fill in beside the phoneme head.
-        // Lowest priority (measured against normal / high: 2.37 vs 2.42 / 2.40 ms one step in flight).
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // (numerically: lowest priority = largest value)
-        if (hipStreamCreateWithPriority(&h->head_stream, hipStreamNonBlocking, prio_lo) == hipSuccess) {
-            if (hipEventCreateWithFlags(&h->head_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&h->head_join, hipEventDisableTiming) != hipSuccess) {
-                (void)hipStreamDestroy(h->head_stream);
-                h->head_stream = nullptr;
-            }
-        }
-        (void)hipSetDevice(prev);
-    }
+    h->num_cu = num_cu;
     *out = h;
     return BFA_OK;
 }
@@ -411,8 +428,8 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
         h->events.push_back(pr);
         ev0 = (void *)pr.first; ev1 = (void *)pr.second;
     }
-    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done, (void *)h->forked,
-                                    h->forked ? h->naux : 0);
+    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done, (void **)&h->forked,
+                                    ensure_aux, (void *)h);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }
@@ -447,6 +464,7 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
     // waits for both: 2.09 -> 1.75 ms one call at a time on four queues.  With several calls in flight (three handles) the
     // six extra streams collide on the queues and the side stream is the better layout (1.46 against 1.66 ms per step):
     // BFA_OPT_CALLS_IN_FLIGHT tells which caller this is.
+    if (n_heads > 1) ensure_head_streams(h);
     const bool paired = n_heads > 1 && !h->calls_in_flight && h->pair[0] && h->pair[1] && h->head_fork;
     const bool side = !paired && n_heads > 1 && h->head_stream != nullptr;
     if (paired) {

@@ -321,7 +321,7 @@ extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *
 }
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void *fork_event, int naux)
+                                void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
@@ -374,8 +374,9 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     fan.main_stream = stream;
     fan.aux = (hipStream_t *)aux_streams;
     fan.joined = (hipEvent_t *)aux_events;
-    fan.forked = (hipEvent_t)fork_event;
-    fan.naux = (n_kernels > 1 && aux_streams) ? naux : 0;
+    // (the handle creates its auxiliary streams when a call first has kernels to run side by side: bfa_capi.cpp ensure_aux)
+    fan.naux = (n_kernels > 1 && aux_streams && ensure_aux) ? ensure_aux(ctx) : 0;
+    fan.forked = fork_event ? (hipEvent_t)*fork_event : nullptr;
     fan.used = 0;
     // several K1 kernels side by side: the window items are walked on the window kernels' stream as soon as those are
     // done (with ONE kernel -- the headline batch -- that would only add a launch to the serial chain)

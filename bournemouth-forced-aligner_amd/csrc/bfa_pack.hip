@@ -210,7 +210,7 @@ extern "C" int bfa_launch_copy(void *dst, const void *src, size_t bytes, void *s
     return (int)hipGetLastError();
 }
 
-extern "C" int64_t bfa_pack_words(int n_cap, int64_t tuple_cap, int has_conf)
+extern "C" __attribute__((visibility("default"))) int64_t bfa_pack_words(int n_cap, int64_t tuple_cap, int has_conf)
 {
     return bfa::pack_layout(n_cap, tuple_cap, has_conf).words;
 }
@@ -224,7 +224,7 @@ extern "C" int bfa_launch_pack(const int32_t *segs, int seg_cap, const int32_t *
     return (int)hipGetLastError();
 }
 
-extern "C" int64_t bfa_pack16_words(int n_cap, int64_t tuple_cap) { return bfa::pack_layout16(n_cap, tuple_cap).words; }
+extern "C" __attribute__((visibility("default"))) int64_t bfa_pack16_words(int n_cap, int64_t tuple_cap) { return bfa::pack_layout16(n_cap, tuple_cap).words; }
 
 extern "C" int bfa_launch_pack16(const int32_t *segs, int seg_cap, const int32_t *seg_count, int n, int n_cap, int tuple_cap,
                                  int32_t *out, void *stream)

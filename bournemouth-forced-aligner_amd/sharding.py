@@ -236,6 +236,15 @@ def gather_packed(record, n_total, dst=0, group=None, out=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     words = record.numel()
+    if record.is_cuda and dist.get_backend(group) == "gloo":
+        # A host-side process group under device-resident records (several ranks sharing ONE GPU: RCCL refuses two ranks on
+        # a device, `bench.py --oversubscribe`): the record leaves the GPU through pinned memory and gloo gathers host tensors;
+        # the receiver reads the records from the host (GatheredRecords' host path).  Same pack kernel, same record layout,
+        # same single gather as over RCCL.
+        host = torch.empty((words,), dtype=torch.int32, pin_memory=True)
+        host.copy_(record, non_blocking=True)
+        torch.cuda.current_stream(record.device).synchronize()
+        record, out = host, None
     bufs = None
     if rank == dst:
         if out is None:

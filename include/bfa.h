@@ -38,6 +38,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden and an export map (csrc/bfa_exports.map): exactly the functions declared in
+ * this header are visible */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define BFA_ABI_VERSION 6 /* v6: bfa_call_counters (what a call's items did: fast windows redone, exact-first routing); v5: bfa_pack_results / bfa_pack_words / bfa_index_records (packed result records); v4: bfa_set_option; v3: bfa_params.min_log_prob (ViterbiDecoder.min_phoneme_prob), bfa_set_tail_stream removed */
 
@@ -339,6 +344,9 @@ int bfa_pack_results16(bfa_handle h, const bfa_segment *segs, int seg_cap, const
 int bfa_index_records(bfa_handle h, const int32_t *records, int world, int64_t words, int n_max, int n_total,
                       int32_t *out_owner, int32_t *out_offset, int32_t *out_count, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,67 @@ def _bench_json(argv, timeout=900):
     return json.loads(lines[0])
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun_bench_json(n, argv, timeout=1800):
+    """what the driver does for N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + argv
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _c4_ranks_share_one_gpu(n, global_batch):
+    out = _torchrun_bench_json(n, ["--config", "c4", "--oversubscribe", "--global-batch", str(global_batch), "--steps", "2",
+                                   "--warmup", "1", "--parity-sample", str(global_batch)])
+    assert out["n_gpus"] == n and len(out["ranks"]) == n
+    assert all(r["device"] == "cuda:0" and r.get("oversubscribed") for r in out["ranks"])
+    assert len({r["pid"] for r in out["ranks"]}) == n and sorted(r["rank"] for r in out["ranks"]) == list(range(n))
+    assert out["group"] == {"backend": "gloo", "ranks_seen": n, "rccl_ranks_seen": None, "oversubscribed": True}
+    assert len(out["shard_sizes"]) == n and sum(out["shard_sizes"]) == global_batch and min(out["shard_sizes"]) > 0
+    assert out["shard_agree"] and len(out["rank_ms_per_step"]) == n and min(out["rank_ms_per_step"]) > 0
+    ps = out["parity_sample"]   # EVERY utterance: re-synthesised on rank 0, its gathered record against the oracle
+    assert ps["utterances"] == global_batch and ps["mismatching_utterances"] == 0 and ps["regenerated_inputs_differing"] == 0
+    assert out["gather"]["payload_bytes"] > 0 and out["frames_per_step"] > global_batch * 200
+    return out
+
+
+def test_c4_two_ranks_share_one_gpu(gpu_device):
+    """N = 2 with REAL GPU work: two processes on the one GPU of the box, a gloo group, every rank
+    synthesises and aligns its LPT shard, packs its records on the device, ONE gather (records staged through pinned host
+    memory: RCCL refuses two ranks on a device), rank 0 indexes the records and checks every utterance against the oracle."""
+    _c4_ranks_share_one_gpu(2, 1024)
+
+
+def test_c4_eight_ranks_share_one_gpu(gpu_device):
+    """the same with the EIGHT ranks of a node: partition -> align -> pack -> gather -> index under N = 8, real results"""
+    _c4_ranks_share_one_gpu(8, 2048)
+
+
+def test_headline_two_ranks_share_one_gpu(gpu_device):
+    """the weak-scaling mode's N > 1 leg with real alignments on both ranks: barriers, max over ranks, the gather of both
+    ranks' records and the comparison of rank 0's gathered rows with its own results"""
+    out = _torchrun_bench_json(2, ["--oversubscribe", "--batch", "512", "--steps", "4", "--warmup", "2", "--no-cpu",
+                                   "--settle-ms", "0", "--min-timed-steps", "8"])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024 and out["gather_ms"] is not None
+    assert out["group"]["backend"] == "gloo" and out["group"]["ranks_seen"] == 2 and out["value"] > 0
+
+
 def test_c4_mode_world_size_1_nccl(gpu_device):
     """BASELINE.json configs[3] end to end at reduced global batch: plan -> LPT shard -> per-rank synthesis and
     alignment in length-sorted calls -> sharding.gather_results over an RCCL process group -> rank 0 re-synthesises a
@@ -40,6 +101,8 @@ def test_c4_mode_world_size_1_nccl(gpu_device):
         assert ps["longest_T"] >= 2990  # the sample holds the longest utterances of the batch
         assert out["shard_sizes"] == [1536] and out["gather_ms"] is not None and out["value"] > 0
         assert out["scaling"] == "strong" and out["frames_per_step"] > 1536 * 200
+        # the communicator itself saw one rank (all_reduce of ones over RCCL): what the driver's SCALE run prints per N
+        assert out["rccl_ranks_seen"] == 1 and out["group"]["backend"] == "nccl"
 
 
 def _batch_vs_oracle(ora, dev, B, T, S, seed, n_check):

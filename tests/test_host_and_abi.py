@@ -28,6 +28,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/bfa.h but not exported"
     assert set(_lib.EXPORTS) <= set(names)
+    # ... and NOTHING else: -fvisibility=hidden + the export map csrc/bfa_exports.map (~60 internal bfa_launch_* /
+    # bfa_k1_* symbols were exported beside the ABI)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TtDdBbWw"}
+        assert exported == set(names), f"exported but not in bfa.h: {sorted(exported - set(names))}; missing: {sorted(set(names) - exported)}"
     lib.bfa_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.bfa_version()
     assert lib.bfa_abi_version() == 6
