@@ -242,12 +242,12 @@ template <bool RAW>
 __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    // [seg_cap] doubles | [seg_cap] tuples | 3 x [seg_cap] ints | [cap_cells] floats
+    // [seg_cap] doubles | [seg_cap] tuples | 4 x [seg_cap] ints | [cap_cells] floats
     double *smean = (double *)dyn_lds;
     bfa_segment *st = (bfa_segment *)(dyn_lds + (size_t)a.seg_cap * 8);
     int32_t *off = (int32_t *)(dyn_lds + (size_t)a.seg_cap * (8 + sizeof(bfa_segment)));
-    int32_t *wlo = off + a.seg_cap, *whi = wlo + a.seg_cap;
-    float *sp = (float *)(whi + a.seg_cap);
+    int32_t *wlo = off + a.seg_cap, *whi = wlo + a.seg_cap, *wfl = whi + a.seg_cap;
+    float *sp = (float *)(wfl + a.seg_cap);
     const int lane = threadIdx.x & 63;
     const double th1 = a.th1, th2 = a.th2;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -294,10 +294,16 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
         int Tc = a.T_rows ? a.T_rows[b] : a.Tmax;     // the confidence pass on log_probs.shape[0] as the caller passes it
         if (Tc > a.Tmax) Tc = a.Tmax;
         const bool staging = (a.do_post && a.extend) || a.do_conf;
-        // ---- the windows: [start - K, end + K) clipped to the rows, K = 0 without the extension passes
-        int total = 0;
-        if (staging) {
-            const int K = (a.do_post && a.extend) ? STAGE_K : 0;
+        const int K = (a.do_post && a.extend) ? STAGE_K : 0;
+        // ---- the windows.  mode 0: [start - K, end + K) clipped to the rows, K = 0 without the extension passes.  mode 1 (the
+        // left walks of passes 1 and 3, see below): a tuple whose flag bit 0 is set reaches up to W frames further to the left,
+        // but never beyond the tuple before it (the passes cannot: core.py:724-728,765); the LAST tuple with bit 1 also to the
+        // right (pass 2 moves no other tuple's end: core.py:745-747).  mode 2 (the right walks of pass 4 and the confidences):
+        // from the tuple's start as it is now to end + K, with bit 1 up to W frames further but never beyond the start of the
+        // tuple after it as it is now (core.py:791-793).  Tuples of an alignment are disjoint runs: every mode needs at most
+        // Tmax + 2 K seg_cap cells.  Returns the number of cells.
+        auto assign_windows = [&](int mode, int W) -> int {
+            int tot = 0;
             for (int base = 0; base < m; base += 64) {
                 const int i = base + lane;
                 int len = 0, lo = 0;
@@ -305,8 +311,18 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                     const bfa_segment g = st[i];
                     const int s0 = max(0, g.start), e0 = min(a.Tmax, g.end);
                     if (g.phoneme >= 0 && g.phoneme < a.C && s0 < a.Tmax) {
-                        lo = max(0, s0 - K);
-                        const int hi = min(a.Tmax, max(e0, s0 + 1) + K);
+                        const int e1 = max(e0, s0 + 1);
+                        int xl = (mode == 2) ? 0 : K, xr = K;
+                        if (mode != 0) {
+                            const int fl = wfl[i];
+                            if (mode == 1 && (fl & 1)) { const int limL = (i > 0) ? min(s0, max(0, st[i - 1].end)) : 0; xl = max(K, min(W, s0 - limL)); }
+                            if ((fl & 2) && (mode == 2 || i == m - 1)) {
+                                const int limR = (i + 1 < m) ? max(e1, min(a.Tmax, st[i + 1].start)) : a.Tmax;
+                                xr = max(K, min(W, limR - e1));
+                            }
+                        }
+                        lo = max(0, s0 - xl);
+                        const int hi = min(a.Tmax, e1 + xr);
                         len = hi - lo;
                     }
                 }
@@ -314,15 +330,13 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                 int incl = len;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-                if (i < m) { off[i] = total + incl - len; wlo[i] = lo; whi[i] = lo + len; }
-                total += __shfl(incl, 63);
+                if (i < m) { off[i] = tot + incl - len; wlo[i] = lo; whi[i] = lo + len; }
+                tot += __shfl(incl, 63);
             }
-            if (total > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
-                for (int i = lane; i < m; i += 64) whi[i] = wlo[i];
-                total = 0;
-            }
-            post_sync();
-            // ---- stage: cell c belongs to the tuple i with off[i] <= c < off[i] + len_i (binary search), frame wlo[i] + (c - off[i])
+            return tot;
+        };
+        // ---- stage: cell c belongs to the tuple i with off[i] <= c < off[i] + len_i (binary search), frame wlo[i] + (c - off[i])
+        auto stage_cells = [&](int total) {
             constexpr int U = 8;
             for (int c0 = 0; c0 < total; c0 += 64 * U) {
                 float x[U];
@@ -347,6 +361,35 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                     if (c0 + u * 64 + lane < total) sp[cell[u]] = exp_cr(v);
                 }
             }
+        };
+        // the widest reach whose cells fit the LDS (a probe beyond it reads memory), staged
+        auto restage = [&](int mode) -> int {
+            post_sync();
+            int W = 1 << 20, tot = 0;
+            for (;;) {
+                tot = assign_windows(mode, W);
+                if (tot <= a.cap_cells || W <= 1) break;
+                W = (W > 256) ? 256 : (W >> 1);
+                post_sync();
+            }
+            if (tot > a.cap_cells) { // (overlapping caller-made tuples: nothing is staged)
+                for (int i = lane; i < m; i += 64) whi[i] = wlo[i];
+                tot = 0;
+            }
+            post_sync();
+            stage_cells(tot);
+            post_sync();
+            return tot;
+        };
+        int total = 0;
+        if (staging) {
+            total = assign_windows(0, 0);
+            if (total > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
+                for (int i = lane; i < m; i += 64) whi[i] = wlo[i];
+                total = 0;
+            }
+            post_sync();
+            stage_cells(total);
             post_sync();
         }
         const StagedProb<RAW> pr{lp, sp, off, wlo, whi};
@@ -364,6 +407,46 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                 smean[i] = mean;
             }
             post_sync();
+            // ---- Can a walk of the passes below leave its tuple's staged window?  Only if every staged margin cell on that side
+            // is at or above the smallest threshold any pass compares it with (the walks stop at the first cell below theirs) and
+            // the window does not already reach the neighbour.  On sharp posteriors no tuple qualifies and this costs 2 K LDS
+            // reads per tuple.  On soft ones (logits N(0,1) + 3 on the planted class: every class keeps ~1e-2, above both
+            // thresholds) EVERY walk runs to its limit -- through memory that was one dependent 64-byte-sector read, a row
+            // statistics read and a float64 exponential per frame and lane: 12.5 ms per head on the C5 proxy against 0.8 ms on
+            // sharp posteriors (profiles/r06_softness_before.jsonl).  Such tuples get windows that reach as far as their passes
+            // can (the gap to the neighbouring tuple): once to the LEFT for passes 1-3, once to the RIGHT -- from the starts as
+            // pass 3 leaves them -- for pass 4 and the confidences, so that either round needs no more cells than the first (a
+            // gap is staged for one neighbour at a time); the cells of the earlier rounds come from the L2, and the walks run at
+            // LDS speed.  The result does not depend on any of this (StagedProb::at).
+            int wide = 0;
+            if (total > 0) {
+                int anyw = 0;
+                for (int i = lane; i < m; i += 64) {
+                    const bfa_segment g = st[i];
+                    int fl = 0;
+                    const int lo = wlo[i], hi = whi[i];
+                    if (hi > lo) {
+                        const int s0 = max(0, g.start), e1 = max(min(a.Tmax, g.end), s0 + 1);
+                        double tmin = smean[i] * th1; if (tmin > th1) tmin = th1; if (th2 < tmin) tmin = th2;
+                        const int limL = (i > 0) ? min(s0, max(0, st[i - 1].end)) : 0;
+                        const int limR = (i + 1 < m) ? max(e1, min(a.Tmax, st[i + 1].start)) : a.Tmax;
+                        if (lo > limL && s0 > lo) {
+                            bool all = true;
+                            for (int f = lo; f < s0; ++f) all = all && ((double)sp[off[i] + (f - lo)] >= tmin);
+                            if (all) fl |= 1;
+                        }
+                        if (hi < limR && hi > e1) {
+                            bool all = true;
+                            for (int f = e1; f < hi; ++f) all = all && ((double)sp[off[i] + (f - lo)] >= tmin);
+                            if (all) fl |= 2;
+                        }
+                    }
+                    wfl[i] = fl;
+                    anyw |= fl;
+                }
+                wide = __any(anyw) ? 1 : 0;
+                if (wide) total = restage(1);
+            }
             // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
             for (int pass = 1; pass <= 4; ++pass) {
                 for (int i = lane; i < m; i += 64) {
@@ -403,6 +486,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                     }
                 }
                 post_sync();
+                if (pass == 3 && wide) total = restage(2);
             }
         }
         if (a.do_post) {
@@ -500,7 +584,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
 static size_t postconf_lds(int Tmax, int seg_cap, int *cap_cells)
 {
     const size_t cells = (size_t)Tmax + 2 * (size_t)bfa::STAGE_K * (size_t)seg_cap + 64;
-    const size_t bytes = (size_t)seg_cap * (8 + sizeof(bfa_segment) + 12) + cells * 4;
+    const size_t bytes = (size_t)seg_cap * (8 + sizeof(bfa_segment) + 16) + cells * 4;
     if (bytes > 60 * 1024) return 0;
     *cap_cells = (int)cells;
     return bytes;

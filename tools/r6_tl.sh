@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd $ROOT
 mkdir -p gpurun_out/r6b
 run() { # tag nplan shape peak
-  bash tools/timeline.sh r6b_$1 $2 python tools/softness.py --shapes $3 --peaks $4 --steps 3 --warmup 2 --parity 4 > gpurun_out/r6b/$1.txt 2>&1
+  bash tools/timeline.sh r6b_$1 $2 python $ROOT/tools/softness.py --shapes $3 --peaks $4 --steps 3 --warmup 2 --parity 4 > gpurun_out/r6b/$1.txt 2>&1
   tail -60 gpurun_out/r6b/$1.txt
 }
 run c5p9 2 c5proxy 9
@@ -11,5 +11,3 @@ run c5p5 2 c5proxy 5
 run c5p3 2 c5proxy 3
 run rt3 2 realtext 3
 run hl6 1 headline 6
-python tools/cold_start.py > gpurun_out/r6b/cold_start.json 2>&1; cat gpurun_out/r6b/cold_start.json
-python tools/cold_start.py >> gpurun_out/r6b/cold_start.json 2>&1
