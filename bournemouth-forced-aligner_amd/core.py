@@ -213,6 +213,50 @@ class PhonemeTimestampAligner:
             raise ValueError("group_sequences not given and no phoneme_id_to_group_id mapping was configured")
         return [self.phoneme_id_to_group_id.get(int(p), self.blank_group) for p in seq]
 
+    # ---- the reference's two public post-DP methods, for callers that use them directly (core.py:462, 682)
+    def ensure_target_coverage(self, phoneme_sequences, aligned_frames, seq_lens=None, _silence_class=0, debug=False):
+        """core.py:462-680 on host lists: rows (phoneme, start, end, target_idx) -> 5-tuples with the `is_estimated` flag.
+        With ensure_completeness the repair of coverage.py; by default rows with target index -1 / beyond the sequence are
+        dropped and the rest stably sorted by start frame (what bfa_postprocess does on the device inside
+        extract_timestamps_from_logits)."""
+        if self.ensure_completeness:
+            return ensure_target_coverage(phoneme_sequences, aligned_frames, seq_lens, _silence_class)
+        out = []
+        for b, rows in enumerate(aligned_frames):
+            seq = phoneme_sequences[b]
+            n = int(seq_lens[b]) if seq_lens is not None else len(seq)
+            keep = sorted((r for r in rows if int(r[3]) != -1 and int(r[3]) < n), key=lambda r: r[1])
+            out.append([tuple(r) if len(r) != 4 else (*r, False) for r in keep])
+        return out
+
+    def extend_soft_boundaries_func(self, log_probs, framestamps, boundary_softness=3, debug=False):
+        """core.py:682-809 for callers that hold log-probs [B, T, C] and lists of (phoneme, start, end, target_idx,
+        is_estimated): the four extension passes on the device (bfa_postprocess), rows returned in the same structure.
+        The device stage works on rows in start-frame order with valid target indices -- what ensure_target_coverage
+        returns; anything else is refused rather than silently reordered."""
+        B = len(framestamps)
+        cap = max(1, max((len(r) for r in framestamps), default=1))
+        host = np.zeros((B, cap, 4), np.int32)
+        cnt = np.zeros(B, np.int32)
+        for b, rows in enumerate(framestamps):
+            starts = [int(r[1]) for r in rows]
+            if any(x > y for x, y in zip(starts, starts[1:])) or any(int(r[3]) < 0 for r in rows):
+                raise ValueError("extend_soft_boundaries_func: rows must be sorted by start frame with target indices >= 0 "
+                                 "(the output of ensure_target_coverage)")
+            if rows:
+                host[b, :len(rows)] = [[int(r[0]), int(r[1]), int(r[2]), int(r[3])] for r in rows]
+            cnt[b] = len(rows)
+        dev = self.device
+        segs, count = torch.from_numpy(host).to(dev), torch.from_numpy(cnt).to(dev)
+        keep_all = torch.full((B,), 2 ** 31 - 1, dtype=torch.int32, device=dev)   # (no row is dropped: indices are < this)
+        postprocess_batch(log_probs.to(dev), keep_all, segs, count, extend=True, boundary_softness=boundary_softness)
+        got, n = _to_host(segs, count)
+        out = []
+        for b, rows in enumerate(framestamps):
+            assert int(n[b]) == len(rows)
+            out.append([(int(r[0]), int(g[1]), int(g[2]), int(r[3])) + tuple(r[4:]) for r, g in zip(rows, got[b])])
+        return out
+
     # ---- one head: align -> coverage -> soft boundaries -> confidences, all on the device
     def _head(self, utils, log_probs, seqs, seq_lens, spectral_lens, aligned=None):
         """One head after the alignment: coverage -> soft boundaries -> confidences on the device.  `aligned` =

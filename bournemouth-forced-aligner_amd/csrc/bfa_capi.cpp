@@ -67,6 +67,18 @@ struct bfa_context {
     // ever aligns single-class batches -- the reference's 16-utterance chunks -- never pays for nine streams and their events
     // (bfa_create 22 ms -> see profiles/r06_cold_start.json).
     bool aux_tried = false, heads_tried = false;
+    // Window routing (BFA_OPT_WINDOW_ROUTING; standard mode on the head widths).  The fast sliding window only stands when an
+    // utterance ends above the reference's -1000 sentinel; a caller whose posteriors lose ~1 log-unit per frame loses it on
+    // every utterance of ~1000 frames, and every call would pay a fast attempt plus the exact rerun.  The last walk kernel of
+    // a call leaves the call's window statistics in host-mapped memory (hist[slot], slot 0: C = 67, 1: C = 17); the next calls
+    // read whatever has landed -- no synchronisation -- and switch: most fast windows gave up -> exact window at once
+    // (XWIN_ROUTE); most exact reruns of a routed call ended above the sentinel -> fast windows again.
+    int routing = 1;              // 0 never, 1 by history, 2 always exact-first
+    int32_t *hist = nullptr;      // [2][8] host-mapped
+    bool hist_tried = false;
+    int route_state[2] = {0, 0};  // what the next call does
+    int hist_seen[2] = {0, 0};    // tag of the statistics the state already reflects
+    int hist_tag[2] = {0, 0};     // tag of the last call issued
 };
 
 namespace {
@@ -333,6 +345,7 @@ int bfa_destroy(bfa_handle h)
         if (h->head_stream) (void)hipStreamDestroy(h->head_stream);
         if (h->head_fork) (void)hipEventDestroy(h->head_fork);
         if (h->head_join) (void)hipEventDestroy(h->head_join);
+        if (h->hist) (void)hipHostFree(h->hist);
     }
     delete h;
     return BFA_OK;
@@ -418,6 +431,35 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
     if (a.p.min_logp != a.p.min_logp) return fail(h, BFA_ERR_INVALID_ARGUMENT, "min_log_prob is NaN");
     a.segs = out_segs; a.seg_cap = seg_cap; a.seg_count = out_seg_count; a.status = out_status; a.mode = out_mode;
 
+    // window routing: standard-mode calls on the head widths (the only ones with fast windows)
+    if ((C == 67 || C == 17) && !segmented_possible(params) && params->boost_targets && params->enforce_minimum && !params->simple) {
+        const int slot = C == 67 ? 0 : 1;
+        if (!h->hist_tried) {
+            h->hist_tried = true;
+            void *hp = nullptr;
+            if (h->routing == 1 && hipHostMalloc(&hp, 2 * 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+                std::memset(hp, 0, 2 * 8 * sizeof(int32_t));
+                h->hist = (int32_t *)hp;
+            }
+        }
+        if (h->routing == 1 && h->hist) {
+            volatile int32_t *v = h->hist + 8 * slot;
+            const int tag = v[0];
+            if (tag != h->hist_seen[slot]) { // statistics of a call this state has not seen yet
+                const int gave_up = v[1], xdone = v[2], xalive = v[3], nB = v[4], routed = v[5];
+                if (v[0] == tag && nB > 0) {
+                    if (!routed && 4 * gave_up >= nB) h->route_state[slot] = 1;             // a quarter of the call or more was redone
+                    else if (routed && xdone > 0 && 10 * xalive >= 9 * xdone) h->route_state[slot] = 0; // the fast window would have done
+                    h->hist_seen[slot] = tag;
+                }
+            }
+            a.hist = h->hist + 8 * slot; // (the host pointer of mapped memory is valid on the device)
+            a.hist_tag = ++h->hist_tag[slot];
+            if (a.hist_tag == 0) a.hist_tag = ++h->hist_tag[slot];
+        }
+        const bool route = h->routing == 2 || (h->routing == 1 && h->route_state[slot] != 0);
+        if (route) a.p.xwin_mask |= bfa::XWIN_ROUTE; // (bfa_launch_align keeps the bit)
+    }
     // one wavefront per work item; surplus items are taken by the blocks' stride loops
     int grid = l.item_cap < 16384 ? l.item_cap : 16384;
     void *ev0 = nullptr, *ev1 = nullptr;
@@ -518,6 +560,11 @@ int bfa_set_option(bfa_handle h, int option, int value)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     if (option == BFA_OPT_CALLS_IN_FLIGHT) { h->calls_in_flight = value != 0; return BFA_OK; }
+    if (option == BFA_OPT_WINDOW_ROUTING) {
+        if (value < 0 || value > 2) return fail(h, BFA_ERR_INVALID_ARGUMENT, "window routing: 0 never, 1 by history, 2 always");
+        h->routing = value; h->route_state[0] = h->route_state[1] = 0;
+        return BFA_OK;
+    }
     return fail(h, BFA_ERR_INVALID_ARGUMENT, "unknown option");
 }
 

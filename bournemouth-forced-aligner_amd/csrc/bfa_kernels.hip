@@ -335,7 +335,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const bool seg_possible = cp.seg_possible, use_mix = cp.use_mix;
     const int mode = cp.mode, rw1 = cp.rw1;
     a.p.win_mask = wmask;
-    a.p.xwin_mask = xmask;
+    a.p.xwin_mask = xmask | ((xmask & XWIN_REDO) ? (p.xwin_mask & XWIN_ROUTE) : 0u); // (routing: the caller's bit, when reruns by the exact window exist)
     // One item per utterance (no silence-anchored pieces) on the 16-rows-per-pass kernels: K2 walks each full-layout
     // class right behind its K1 kernel on that kernel's stream, the window classes after the sentinel reruns, and
     // emits the run-length tuples during the walk -- no K3a launch.

@@ -57,6 +57,12 @@ __host__ __device__ inline int piece_bucket(int Ts, int Tmax)
     return b < 0 ? 0 : (b >= PIECE_BUCKETS ? PIECE_BUCKETS - 1 : b);
 }
 constexpr uint32_t XWIN_REDO = 0x100u, XWIN_MIX = 0x200u;
+// XWIN_ROUTE (round 6): the caller's last calls lost most of their fast windows to the sentinel (bfa_capi.cpp: window routing):
+// k_plan hands every fast-window item with a stride >= 3 to the exact rerun kernels at once (XW_REDO), no fast attempt.
+constexpr uint32_t XWIN_ROUTE = 0x400u;
+// counters[] slots of the exact reruns, standard mode only (the silence-anchored mode keeps its piece counts there):
+// items the exact rerun kernels aligned / how many of them ended ABOVE the sentinel (the fast window would have done)
+constexpr int CNT_XDONE = 4, CNT_XALIVE = 5;
 constexpr int ONE_MAX_BATCH = 1024; // largest single-class call that takes the one-kernel path (k_one; 8192: 0.62 ms against 0.32 + 0.06 for the headline batch)
 #ifndef BFA_MIX_MIN_BATCH
 #define BFA_MIX_MIN_BATCH 2
@@ -152,6 +158,10 @@ struct AlignArgs {
     // the list of its length bucket (counters[PIECE_CNT0 + bucket] entries in piece_list[bucket * item_cap ..]); workgroup
     // B + k of k_dp4_any takes the k-th entry counting from the longest bucket down (bfa_dp4.inc: any_item)
     int32_t *piece_list;
+    // window routing (bfa_capi.cpp): 8 ints of host-mapped memory the last walk kernel of a standard-mode call leaves this
+    // call's window statistics in ({tag, fast windows that gave up, exact reruns, of those alive, B, routed}); nullptr = off
+    int32_t *hist;
+    int32_t hist_tag;
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_XWIN = 5, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
 constexpr int K2_NARROW = 64; // | (class bits of the merged narrow full-layout classes << 8): K2_WIN + those classes (k_dp4w_any)

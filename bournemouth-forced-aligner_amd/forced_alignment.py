@@ -256,18 +256,18 @@ class AlignmentResult:
 
     def call_counters(self):
         """Diagnostics (bfa_call_counters; synchronises): what the items of the call that produced this result did --
-        {"items", "routed_exact", "redone_full", "redone_exact"}.  Only valid until the decoder's next call (the counters
+        {"items", "redone_full", "redone_exact" (fast windows that gave up), "exact_done" / "exact_alive" (standard mode: items the exact rerun kernels aligned / of those above the sentinel)}.  Only valid until the decoder's next call (the counters
         live in its workspace)."""
         B, Tmax, Smax, C, params, ws, dev = self._call
         L = _lib.lib()
-        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+        h = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())  # (any handle: the counters live in the workspace)
         out = (ctypes.c_int32 * 16)()
         with torch.cuda.device(dev):
             rc = L.bfa_call_counters(h, ws.data_ptr(), B, Tmax, Smax, C, ctypes.byref(params), out,
                                      torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, h, "bfa_call_counters")
-        return {"items": int(out[0]), "routed_exact": int(out[1]), "redone_full": int(out[2]), "redone_exact": int(out[3]),
-                "raw": [int(v) for v in out]}
+        return {"items": int(out[0]), "redone_full": int(out[2]), "redone_exact": int(out[3]), "exact_done": int(out[4]),
+                "exact_alive": int(out[5]), "raw": [int(v) for v in out]}
 
     def to_lists(self, check_status=False):
         """list[B] of list[(phoneme_id, start_frame, end_frame, target_seq_idx)] (forced_alignment.py:871).

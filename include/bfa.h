@@ -155,9 +155,10 @@ size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p
 
 /* Diagnostics of the LAST bfa_align_batch / bfa_align_heads call that used `workspace` (same shapes and params as that call):
  * copies sixteen int32 device counters to `out_host` and waits for `stream`.  [0] work items (utterances + silence-anchored
- * pieces); [2] sliding-window items that ended at the reference's -1000 sentinel and were redone with the full layout; [3]
- * the same, redone with the exact window; [1] utterances the window routing sent to the exact window at once (see
- * bfa.h BFA_OPT_WINDOW_ROUTING); [4..15] piece counts per length bucket (silence-anchored mode).  Not on any hot path. */
+ * pieces); [2] sliding-window items that gave up (dead or doomed at the reference's -1000 sentinel) and were redone with the
+ * full layout; [3] the same, redone with the exact window; standard mode: [4] items the exact rerun kernels aligned (those
+ * of [3] plus the ones BFA_OPT_WINDOW_ROUTING handed over at once), [5] how many of them ended above the sentinel;
+ * silence-anchored mode: [1] candidate utterances, [4..15] piece counts per length bucket.  Not on any hot path. */
 int bfa_call_counters(bfa_handle h, const void *workspace, int B, int Tmax, int Smax, int C, const bfa_params *p,
                       int32_t *out_host, void *stream);
 
@@ -266,8 +267,17 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
  *       hardware queues even with the runtime's default of four, and share the machine from the first kernel on.
  *       1: the caller keeps several calls in flight on several handles / streams (BatchesInFlight): head 0 stays on the
  *       caller's stream, the others go to one low-priority side stream -- fewer streams per call, the calls overlap each other.
+ *   BFA_OPT_WINDOW_ROUTING  1 (default): standard-mode calls on the head widths go by the handle's recent calls.  The fast
+ *       sliding window of K1 only stands when an utterance ends above the reference's -1000 sentinel
+ *       (forced_alignment.py:23,656-682); posteriors that lose ~1 log-unit per frame end every utterance of ~1000 frames below
+ *       it, and each call would pay a fast attempt plus the rerun by the exact window.  The last kernel of a call leaves its
+ *       window statistics in host-mapped memory of the handle; the following calls read what has landed (no
+ *       synchronisation, possibly a call or two late) and, when a quarter or more of a call's fast windows gave up, hand
+ *       every window item to the exact window at once -- until nine in ten of a routed call's items end above the sentinel
+ *       again.  0: never (a fast attempt first, always), 2: always the exact window first.  Results are identical in all three.
  */
 #define BFA_OPT_CALLS_IN_FLIGHT 1
+#define BFA_OPT_WINDOW_ROUTING 2
 int bfa_set_option(bfa_handle h, int option, int value);
 
 /*

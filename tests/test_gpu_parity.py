@@ -2,11 +2,16 @@
 Integer outputs (framewise states, boundaries, target indices) must be bit-exact; confidences are
 compared bit-exact as well (both sides use the same restated float32 exp), with the north-star
 tolerance 1e-4 as the hard bound."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -802,3 +807,72 @@ def test_uniform_lengths_hint_only_moves_the_work(ora, gpu_device):
                 assert torch.equal(getattr(plain, name)[b, :T_len[b]], getattr(moved, name)[b, :T_len[b]]), (B, T, S, b, name)
         exp = ora.decode_alignments(lp, tk, T_len, S_len, ora.make_params(C - 1, 0, 10, True, True, True, True))
         _compare(moved, exp, T_len)
+
+
+def _softness_args(**kw):
+    import argparse
+    d = dict(sigma=1.0, batch=128, frames=1000, tokens=40, tlo=300, thi=1870, tok_div=12, steps=1, warmup=1, parity=128)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+@pytest.mark.parametrize("peak", [7.0, 3.0])
+def test_soft_posteriors_standard_mode_every_utterance(gpu_device, peak):
+    """OFF the planted peak-9 generator (tools/softness.py): logits N(0,1) + peak on the planted class.
+    At peak 7 most 1000-frame utterances end below the reference's -1000 sentinel (forced_alignment.py:23,656-682), at peak 3
+    all do: the fast window gives up (by extrapolation or when dead) and the exact window aligns the item, closed-form dead tail
+    included.  Uniform call (the headline shape) and one mixed-length call (k_mix + the wide classes), every utterance against
+    the oracle."""
+    sys.path.insert(0, ROOT)
+    from tools import softness
+    for shape, kw in (("headline", dict(batch=192)), ("mixed", dict(batch=160))):
+        a = _softness_args(**kw)
+        a.parity = a.batch
+        rec = softness.run_standard(a, shape, peak, gpu_device)
+        assert rec["status_ok"], rec
+        assert rec["parity"]["utterances"] >= a.batch * 0.9 and rec["parity"]["mismatching_utterances"] == 0, rec
+        if shape == "headline":
+            it = rec["items"]
+            if peak == 3.0:   # every item through the exact window: after a fast window that gave up, or routed there at once
+                assert it["exact_done"] == a.batch and it["exact_alive"] == 0 and rec["sample_share_at_sentinel"] == 1.0, rec
+            else:
+                assert 0 < it["exact_done"], rec
+
+
+def test_soft_posteriors_real_text_chain(gpu_device):
+    """The softest setting of the C5 proxy (bench.py --config c5proxy --peak 3): both heads from raw logits, mixed lengths up to
+    1 870 frames (30 s), SIL in the targets.  Nothing is silence-anchored any more (every utterance takes its standard-mode
+    fallback, most of them in the sentinel regime), every class of every posterior is above both soft-boundary thresholds, so
+    every extension walk of core.py:717-805 runs to its limit -- k_postconf's wide windows.  Rows after coverage + soft
+    boundaries bit-exact and confidences within 1e-4 against the oracle's whole chain, every utterance, both heads."""
+    sys.path.insert(0, ROOT)
+    from tools import softness
+    for shape, peak, B in (("c5proxy", 3.0, 72), ("c5proxy", 6.0, 48), ("realtext", 5.0, 64)):
+        a = _softness_args(batch=B)
+        a.parity = 2 * B
+        rec = softness.run_heads(a, shape, peak, gpu_device)
+        assert rec["status_ok"], rec
+        p = rec["parity"]
+        assert p["utterances"] >= B * 0.9 and p["mismatching_utterances"] == 0 and p["confidence_beyond_1e-4"] == 0, rec
+
+
+def test_reference_post_dp_methods_on_the_mirror_class(ora, gpu_device):
+    """PhonemeTimestampAligner.ensure_target_coverage / extend_soft_boundaries_func (core.py:462, 682) called directly, the way
+    a user of the reference class may: host lists in, host lists out, against the oracle's restatement of both."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils
+    from bournemouth_forced_aligner_amd.core import PhonemeTimestampAligner
+    rng = np.random.default_rng(77)
+    C = 67
+    lp, tk, T_len, S_len = _mk_batch(rng, 12, C, (120, 500), (5, 40), peak=5.0, sigma=1.2, sil_rate=0.1, sil_len=(10, 30))
+    lpd = torch.from_numpy(lp).to(gpu_device)
+    rows = AlignmentUtils(C - 1, 0).decode_alignments(lpd, torch.from_numpy(tk), T_len, S_len)
+    al = PhonemeTimestampAligner(device=str(gpu_device))
+    seqs = [tk[b, :S_len[b]].tolist() for b in range(len(rows))]
+    cov = al.ensure_target_coverage(seqs, [list(r) for r in rows], seq_lens=S_len)
+    ext = al.extend_soft_boundaries_func(lpd, cov, boundary_softness=3)
+    for b in range(len(rows)):
+        want_cov = ora.ensure_target_coverage_default([tuple(r) for r in rows[b]], int(S_len[b]))
+        assert [tuple(r[:4]) for r in cov[b]] == [tuple(r[:4]) for r in want_cov] and all(r[4] is False for r in cov[b])
+        want = ora.extend_soft_boundaries(lp[b], want_cov, 3) if want_cov else []
+        assert [tuple(r[:4]) for r in ext[b]] == [tuple(e[:4]) for e in want], f"item {b}"
+        assert all(len(r) == 5 for r in ext[b])

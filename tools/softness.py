@@ -136,7 +136,7 @@ def run_standard(args, shape, peak, dev):
     return {"shape": shape, "peak": peak, "sigma": args.sigma, "B": int(B), "frames": frames, "launch_path": int(path),
             "ms_per_call": ms, "frames_per_s": frames / (ms * 1e-3), "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "path_logp_per_frame": lpf, "sample_share_at_sentinel": dead,
-            "items": {k: cnt[k] for k in ("items", "routed_exact", "redone_full", "redone_exact")},
+            "items": {k: cnt[k] for k in ("items", "redone_full", "redone_exact", "exact_done", "exact_alive")},
             "status_ok": bool((st == 0).all()), "parity": parity_standard(lp, tk, Tl, Sl, res, C, sample)}
 
 
@@ -191,13 +191,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--parity", type=int, default=48)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--routing", type=int, default=1, help="BFA_OPT_WINDOW_ROUTING of the handle: 0 never, 1 by history, 2 always")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    from bournemouth_forced_aligner_amd import _lib
+    _lib.set_window_routing(0, 0, args.routing)
     out = open(args.out, "a") if args.out else None
     for shape in args.shapes.split(","):
         for pk in [float(v) for v in args.peaks.split(",")]:
             rec = (run_standard if shape in ("headline", "mixed") else run_heads)(args, shape, pk, dev)
+            rec["window_routing"] = args.routing
             line = json.dumps(rec)
             print(line, flush=True)
             if out:
