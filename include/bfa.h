@@ -272,9 +272,9 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
  *       (forced_alignment.py:23,656-682); posteriors that lose ~1 log-unit per frame end every utterance of ~1000 frames below
  *       it, and each call would pay a fast attempt plus the rerun by the exact window.  The last kernel of a call leaves its
  *       window statistics in host-mapped memory of the handle; the following calls read what has landed (no
- *       synchronisation, possibly a call or two late) and, when a quarter or more of a call's fast windows gave up, hand
- *       every window item to the exact window at once -- until nine in ten of a routed call's items end above the sentinel
- *       again.  0: never (a fast attempt first, always), 2: always the exact window first.  Results are identical in all three.
+ *       synchronisation, possibly a call or two late) and, when one in 64 or more of a call's fast windows gave up (the
+ *       rerun behind them is a second serial chain however few they are), hand every window item to the exact window at once
+ *       -- until 99 in 100 of a routed call's items end above the sentinel again.  0: never (a fast attempt first, always), 2: always the exact window first.  Results are identical in all three.
  */
 #define BFA_OPT_CALLS_IN_FLIGHT 1
 #define BFA_OPT_WINDOW_ROUTING 2

@@ -26,7 +26,9 @@ lut = group_lut()
 gmap = {p: int(lut[p]) for p in range(66)}
 al = PhonemeTimestampAligner(device="cuda:0", phoneme_id_to_group_id=gmap)
 ap, ag = AlignmentUtils(66, 0), AlignmentUtils(16, 0)
-for B in (1, 4, 16, 64):
+BS = [int(v) for v in os.environ.get("BFA_BS", "1,4,16,64").split(",")]
+DEVICE_ONLY = bool(int(os.environ.get("BFA_DEVICE_ONLY", "0")))   # (kernel timelines: a few alignment calls, nothing else)
+for B in BS:
     xp, xg, tp, tg, Tl, Sl = synth_realtext_ragged(B, 300, 1870, tok_div, 3000 + B, dev, peak=peak, gpeak=max(1.0, peak - 2.0))
     Tn, Sn = Tl.numpy().astype(np.int64), Sl.numpy().astype(np.int64)
     Td, Sd = Tl.to(dev), Sl.to(dev)
@@ -37,6 +39,8 @@ for B in (1, 4, 16, 64):
         r = fn()
     torch.cuda.synchronize()
     assert all(int((x[0].status != 0).sum()) == 0 for x in r)
+    if DEVICE_ONLY:
+        continue
     n = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
