@@ -14,6 +14,7 @@ BFA_ERR_WORKSPACE_TOO_SMALL, BFA_ERR_UNSUPPORTED = -4, -5
 ITEM_OK, ITEM_TOO_SHORT, ITEM_BAD_TOKEN, ITEM_TOO_LARGE, ITEM_SEG_OVERFLOW, ITEM_BAD_HINT = 0, 1, 2, 3, 4, 5
 HINT_NO_SILENCE_TARGETS = 1 << 16
 HINT_UNIFORM_LENGTHS = 1 << 17
+OPT_WIDE_ANY_MAX_BATCH = 3  # bfa_set_option: silence-anchored calls up to this many utterances take the wide classes as one launch
 OPT_WINDOW_ROUTING = 2  # bfa_set_option: 0 fast window first always, 1 by the handle's history (default), 2 exact window first always
 OPT_CALLS_IN_FLIGHT = 1  # bfa_set_option: the caller keeps several bfa_align_heads calls in flight (BatchesInFlight)
 MIX_MIN_BATCH = 2   # bfa_types.hpp: calls of at least this many utterances with non-uniform lengths take the one-kernel mixed path (k_mix)

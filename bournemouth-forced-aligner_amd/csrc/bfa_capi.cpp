@@ -15,7 +15,8 @@
 #include "bfa_types.hpp"
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx);
+                                void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx,
+                                int aux_first, int aux_count);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
@@ -52,7 +53,7 @@ struct bfa_context {
     static constexpr int NAUX = 6;
     hipStream_t aux[NAUX] = {};
     hipEvent_t aux_done[NAUX] = {};
-    hipEvent_t forked = nullptr;
+    hipEvent_t forked = nullptr, forked_b = nullptr; // (_b: the second head of a bfa_align_heads call)
     int naux = 0;
     // bfa_align_heads: heads after the first are enqueued on this stream (forked from / joined into the caller's)
     hipStream_t head_stream = nullptr;
@@ -73,6 +74,7 @@ struct bfa_context {
     // a call leaves the call's window statistics in host-mapped memory (hist[slot], slot 0: C = 67, 1: C = 17); the next calls
     // read whatever has landed -- no synchronisation -- and switch: most fast windows gave up -> exact window at once
     // (XWIN_ROUTE); most exact reruns of a routed call ended above the sentinel -> fast windows again.
+    int wide_any_max = 256;       // BFA_OPT_WIDE_ANY_MAX_BATCH
     int routing = 1;              // 0 never, 1 by history, 2 always exact-first
     int32_t *hist = nullptr;      // [2][8] host-mapped
     bool hist_tried = false;
@@ -206,13 +208,21 @@ int ensure_aux(void *ctx)
     bfa_context *h = (bfa_context *)ctx;
     if (h->aux_tried) return h->forked ? h->naux : 0;
     h->aux_tried = true;
-    bool ok = hipEventCreateWithFlags(&h->forked, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipEventCreateWithFlags(&h->forked, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->forked_b, hipEventDisableTiming) == hipSuccess;
     if (!ok) h->forked = nullptr;
-    for (int k = 0; ok && k < bfa_context::NAUX; ++k) {
+    // Created in the order 0, 3, 1, 4, 2, 5: the runtime deals streams to its hardware queues (four by default) in turn, and
+    // the two halves (bfa_align_heads: one per head) should not start on the same queue -- nor, when the heads' own streams
+    // were created just before (ensure_head_streams), on the other head's (best effort: the mapping is the runtime's).
+    static const int order[bfa_context::NAUX] = {0, 3, 1, 4, 2, 5};
+    int made = 0;
+    for (int j = 0; ok && j < bfa_context::NAUX; ++j) {
+        const int k = order[j];
         ok = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&h->aux_done[k], hipEventDisableTiming) == hipSuccess;
-        if (ok) h->naux = k + 1;
+        if (ok) ++made;
     }
+    h->naux = made == bfa_context::NAUX ? made : 0;
     return h->forked ? h->naux : 0;
 }
 
@@ -338,6 +348,7 @@ int bfa_destroy(bfa_handle h)
             if (h->aux_done[k]) (void)hipEventDestroy(h->aux_done[k]);
         }
         if (h->forked) (void)hipEventDestroy(h->forked);
+        if (h->forked_b) (void)hipEventDestroy(h->forked_b);
         for (int k = 0; k < 2; ++k) {
             if (h->pair[k]) (void)hipStreamDestroy(h->pair[k]);
             if (h->pair_join[k]) (void)hipEventDestroy(h->pair_join[k]);
@@ -384,7 +395,7 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
                     const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
                     const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
                     bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
-                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream)
+                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream, int aux_set = -1)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(h);
@@ -474,8 +485,13 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
         h->events.push_back(pr);
         ev0 = (void *)pr.first; ev1 = (void *)pr.second;
     }
-    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done, (void **)&h->forked,
-                                    ensure_aux, (void *)h);
+    a.wide_any_max = h->wide_any_max;
+    // the heads of one bfa_align_heads call fan out over DIFFERENT halves of the handle's auxiliary streams (aux_set 0 / 1:
+    // three streams each -- the class kernels are laid out on three, bfa_dp3.inc launch3): on the same ones the class kernels
+    // of the second head queued behind the first head's (profiles/r06_latency_realtext_timeline_b16_before.txt)
+    const int half = bfa_context::NAUX / 2;
+    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done,
+                                    (void **)((aux_set > 0 && (aux_set & 1)) ? &h->forked_b : &h->forked), ensure_aux, (void *)h, aux_set < 0 ? 0 : half * (aux_set & 1), aux_set < 0 ? bfa_context::NAUX : half);
     if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }
@@ -529,7 +545,7 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
         void *st = paired ? (void *)h->pair[k & 1] : ((side && k > 0) ? (void *)h->head_stream : stream);
         rc = align_impl(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, T_len, hd.tokens, S_len,
                         hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
-                        hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st);
+                        hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st, n_heads > 1 ? k : -1);
         // core.py:925-937 for this head on ITS stream: coverage + soft boundaries, then the confidences of the final tuples
         // -- in ONE kernel when both are asked for and the shapes fit its LDS staging (bfa_post.hip: k_postconf)
         if (rc == BFA_OK && hd.postprocess && hd.out_conf && staged_post() && hd.seg_cap <= 6500) {
@@ -564,6 +580,7 @@ int bfa_set_option(bfa_handle h, int option, int value)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     if (option == BFA_OPT_CALLS_IN_FLIGHT) { h->calls_in_flight = value != 0; return BFA_OK; }
+    if (option == BFA_OPT_WIDE_ANY_MAX_BATCH) { h->wide_any_max = value < 0 ? 0 : value; return BFA_OK; }
     if (option == BFA_OPT_WINDOW_ROUTING) {
         if (value < 0 || value > 2) return fail(h, BFA_ERR_INVALID_ARGUMENT, "window routing: 0 never, 1 by history, 2 always");
         h->routing = value; h->route_state[0] = h->route_state[1] = 0;

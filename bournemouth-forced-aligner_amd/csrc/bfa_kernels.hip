@@ -321,7 +321,8 @@ extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *
 }
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
-                                void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx)
+                                void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx,
+                                int aux_first, int aux_count)
 {
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
@@ -372,10 +373,12 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + __builtin_popcount(xmask & 0xafu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0) + (use_mix ? 1 : 0);
     LaunchFan fan;
     fan.main_stream = stream;
-    fan.aux = (hipStream_t *)aux_streams;
-    fan.joined = (hipEvent_t *)aux_events;
+    fan.aux = (hipStream_t *)aux_streams + aux_first;   // (the caller's share of the handle's streams: bfa_align_heads gives each head its own)
+    fan.joined = (hipEvent_t *)aux_events + aux_first;
     // (the handle creates its auxiliary streams when a call first has kernels to run side by side: bfa_capi.cpp ensure_aux)
     fan.naux = (n_kernels > 1 && aux_streams && ensure_aux) ? ensure_aux(ctx) : 0;
+    fan.naux = fan.naux - aux_first < aux_count ? fan.naux - aux_first : aux_count;
+    if (fan.naux < 0) fan.naux = 0;
     fan.forked = fork_event ? (hipEvent_t)*fork_event : nullptr;
     fan.used = 0;
     // several K1 kernels side by side: the window items are walked on the window kernels' stream as soon as those are

@@ -256,6 +256,7 @@ struct PlanScratch {
     int32_t *groups, *aud, *sub, *match;
     SegRec *segs;
     int aud_cap;
+    int groups_cap; // cooperative mode: pairs the LDS group / match arrays hold (the segment records: 2 groups_cap + 4)
     float *cs; // LDS, cooperative mode only
     int32_t *pbk; // LDS, cooperative mode only: the length bucket of every emitted piece (-1: not a DP piece)
     int32_t *gsub; // cooperative mode: the utterance's global sub-silence scratch, for a piece whose runs overflow the LDS array
@@ -307,11 +308,18 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
                 if (rest == 0ull) break;
                 const int j = pos + __builtin_ctzll(rest);
                 if (!in_g) { in_g = true; st = base + j; }
-                else { in_g = false; groups[2 * ng] = st; groups[2 * ng + 1] = base + j; ++ng; }
+                else {
+                    in_g = false;
+                    if (ng + 1 >= sc.groups_cap) return false; // more SIL groups than the LDS arrays hold (nothing written yet): the global scratch
+                    groups[2 * ng] = st; groups[2 * ng + 1] = base + j; ++ng;
+                }
                 pos = j + 1;
             }
         }
-        if (in_g) { groups[2 * ng] = st; groups[2 * ng + 1] = S; ++ng; }
+        if (in_g) {
+            if (ng + 1 >= sc.groups_cap) return false;
+            groups[2 * ng] = st; groups[2 * ng + 1] = S; ++ng;
+        }
     } else {
         for (int i = 0; i < S;) {
             if (tok[i] == p.sil) { const int st = i; while (i < S && tok[i] == p.sil) ++i; groups[2 * ng] = st; groups[2 * ng + 1] = i; ++ng; }
@@ -555,7 +563,7 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
 #define BFA_PLAN_WGS 2048 // workgroups of k_plan_seg = eight per CU (compile-time A/B knob; profiles/r05_plan_grid_ab.txt)
 #endif
 constexpr int PLAN_LDS_FRAMES = 2048;
-constexpr int PLAN_LDS_SILS = 128;  // audio silences / sub-silences (pairs)
+constexpr int PLAN_LDS_SILS = 192;  // audio silences / sub-silences (pairs)
 constexpr int PLAN_LDS_GROUPS = 64; // target SIL groups / matches (pairs)
 
 // `lds_frames` (a multiple of 64, <= PLAN_LDS_FRAMES): frames of the staged cumulative sums -- sized by the batch's Tmax,
@@ -587,8 +595,13 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, in
         // budget of the cooperative path: T / min_k + 1 silence runs (min_k = anchors, or 3 on the S > 200 retry) -- real
         // posteriors stay far below it; the true worst case is ~nwin / 2 overlapping runs, which overflows the scratch and
         // is reported per utterance (see plan_candidate).  SIL groups alternate with other tokens: (S + 1) / 2 at most
-        const int min_k = (S > 200 && a.p.anchors > 3) ? 3 : (a.p.anchors > 0 ? a.p.anchors : 1);
-        const bool coop = T <= lds_frames && (T / min_k + 2 <= sils_cap) && ((S + 1) / 2 + 1 <= groups_cap);
+        // Round 6: the cooperative path is tried whenever the frames fit; the run / group arrays are checked WHILE planning
+        // (plan_candidate returns false before anything is written).  Until then the test was the worst case -- T / min_k + 2
+        // silence runs, (S + 1) / 2 + 1 groups against arrays of 128 / 64 -- which sent every utterance of more than 1 260 frames or
+        // 125 targets to the one-lane path below: 445 us for ONE 20-s utterance (profiles/r06_latency_realtext_timeline_b1_before.txt),
+        // a quarter of the C5 proxy's utterances, 1.6-2.2 ms of planner per call; real posteriors hold a handful of either.
+        (void)S;
+        const bool coop = T <= lds_frames;
         __builtin_amdgcn_wave_barrier(); // the previous candidate's readers are done
         PlanScratch sc;
         bool planned = false;
@@ -601,7 +614,7 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, in
 #ifdef BFA_PLAN_STAMPS
             if (lane == 0) (reinterpret_cast<unsigned long long *>(gscr) + 1)[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-            sc.aud_cap = sils_cap; sc.cs = scs; sc.pbk = s_pbk;
+            sc.aud_cap = sils_cap; sc.groups_cap = groups_cap; sc.cs = scs; sc.pbk = s_pbk;
 #pragma unroll 8
             for (int i = lane; i < T; i += 64) sps[i] = ps[i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -617,7 +630,7 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, in
             sc.sub = scr; scr += 2 * (a.Tmax + 2);
             sc.match = scr; scr += 2 * (a.Smax + 2);
             sc.segs = (SegRec *)scr;
-            sc.aud_cap = a.Tmax + 2; sc.cs = nullptr; sc.gsub = nullptr; sc.gsub_cap = 0; sc.pbk = nullptr;
+            sc.aud_cap = a.Tmax + 2; sc.groups_cap = a.Smax + 2; sc.cs = nullptr; sc.gsub = nullptr; sc.gsub_cap = 0; sc.pbk = nullptr;
             (void)plan_candidate<false>(a, b, ps, sc, lane);
         }
     }

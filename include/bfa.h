@@ -275,9 +275,13 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
  *       synchronisation, possibly a call or two late) and, when one in 64 or more of a call's fast windows gave up (the
  *       rerun behind them is a second serial chain however few they are), hand every window item to the exact window at once
  *       -- until 99 in 100 of a routed call's items end above the sentinel again.  0: never (a fast attempt first, always), 2: always the exact window first.  Results are identical in all three.
+ *   BFA_OPT_WIDE_ANY_MAX_BATCH  256 (default): silence-anchored calls of at most this many utterances run every item of the wide
+ *       CTC-path classes (more than 192 states) in ONE kernel instead of a kernel per class and item kind -- on an empty
+ *       machine the launches are the cost, on a full one the registers of the widest class are (0 = never).
  */
 #define BFA_OPT_CALLS_IN_FLIGHT 1
 #define BFA_OPT_WINDOW_ROUTING 2
+#define BFA_OPT_WIDE_ANY_MAX_BATCH 3
 int bfa_set_option(bfa_handle h, int option, int value);
 
 /*
