@@ -74,7 +74,7 @@ struct bfa_context {
     // a call leaves the call's window statistics in host-mapped memory (hist[slot], slot 0: C = 67, 1: C = 17); the next calls
     // read whatever has landed -- no synchronisation -- and switch: most fast windows gave up -> exact window at once
     // (XWIN_ROUTE); most exact reruns of a routed call ended above the sentinel -> fast windows again.
-    int wide_any_max = 256;       // BFA_OPT_WIDE_ANY_MAX_BATCH
+    int wide_any_max = 256;       // BFA_OPT_WIDE_ANY_MAX_BATCH (< 0: the class kernels of rounds 2-5 for slots AND pieces)
     int routing = 1;              // 0 never, 1 by history, 2 always exact-first
     int32_t *hist = nullptr;      // [2][8] host-mapped
     bool hist_tried = false;
@@ -486,6 +486,7 @@ static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t
         ev0 = (void *)pr.first; ev1 = (void *)pr.second;
     }
     a.wide_any_max = h->wide_any_max;
+    a.pieces_merged = h->wide_any_max >= 0 ? 1 : 0;
     // the heads of one bfa_align_heads call fan out over DIFFERENT halves of the handle's auxiliary streams (aux_set 0 / 1:
     // three streams each -- the class kernels are laid out on three, bfa_dp3.inc launch3): on the same ones the class kernels
     // of the second head queued behind the first head's (profiles/r06_latency_realtext_timeline_b16_before.txt)
@@ -580,7 +581,7 @@ int bfa_set_option(bfa_handle h, int option, int value)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     if (option == BFA_OPT_CALLS_IN_FLIGHT) { h->calls_in_flight = value != 0; return BFA_OK; }
-    if (option == BFA_OPT_WIDE_ANY_MAX_BATCH) { h->wide_any_max = value < 0 ? 0 : value; return BFA_OK; }
+    if (option == BFA_OPT_WIDE_ANY_MAX_BATCH) { h->wide_any_max = value; return BFA_OK; }
     if (option == BFA_OPT_WINDOW_ROUTING) {
         if (value < 0 || value > 2) return fail(h, BFA_ERR_INVALID_ARGUMENT, "window routing: 0 never, 1 by history, 2 always");
         h->routing = value; h->route_state[0] = h->route_state[1] = 0;

@@ -468,7 +468,15 @@ __device__ bool plan_candidate(const AlignArgs &a, int b, const float *ps, const
             it.kind = ITEM_DP; it.row0 = psx; it.Ts = Ts; it.stride = stride; it.L = L;
             it.bw = (L > 60) ? ((L / 3 > 30) ? L / 3 : 30) : 0; // :441
             it.pad_left = s.a0 - psx;
-            bp_off += bp_dwords(Ts, L);
+            {   // backpointers of the piece.  The wide classes (R >= 4) are aligned by two consumer waves (k_dp5_any, round 6), whose
+                // layout -- 2 R lane masks per frame -- is that of the full layout with ALL 64 lanes, 16-byte aligned; the
+                // narrow ones keep the dwords of the lanes that own a state.  (bfa_workspace_bytes bounds either: it counts 64
+                // lanes per quad of every piece.)
+                const int Rp = r_class_for_L(L);
+                const int64_t quads = (Ts + 3) / 4;
+                if (Rp >= 4) bp_off += (quads * bp_words_for_R(Rp) * 64 + quads + 3) & ~(int64_t)3;
+                else bp_off = (bp_off + bp_dwords(Ts, L) + 3) & ~(int64_t)3;
+            }
             // sub-silences of the padded slice get +5 on blank and a re-normalisation, once per
             // (possibly overlapping) detected segment (:415-419, :543-561)
             int nsub = silences(ps + psx, Ts, 0.8f, mf, sub, aud_cap);

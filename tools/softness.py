@@ -191,12 +191,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--parity", type=int, default=48)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--wide-any-max", type=int, default=None, help="BFA_OPT_WIDE_ANY_MAX_BATCH of the handle (A/B)")
     ap.add_argument("--routing", type=int, default=1, help="BFA_OPT_WINDOW_ROUTING of the handle: 0 never, 1 by history, 2 always")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     from bournemouth_forced_aligner_amd import _lib
     _lib.set_window_routing(0, 0, args.routing)
+    if args.wide_any_max is not None:
+        _lib.check(_lib.lib().bfa_set_option(_lib.handle(0, 0), _lib.OPT_WIDE_ANY_MAX_BATCH, args.wide_any_max), _lib.handle(0, 0), "bfa_set_option")
     out = open(args.out, "a") if args.out else None
     for shape in args.shapes.split(","):
         for pk in [float(v) for v in args.peaks.split(",")]:
