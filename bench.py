@@ -26,6 +26,13 @@ processes.  `n_gpus` in the JSON line is the world size the process group report
       the path real transcripts take: raw logits of both heads, SIL in the targets (silence-anchored mode),
       bfa_align_heads + bfa_postprocess + bfa_confidences per step; 512-utterance oracle parity count in the line.
 
+  python bench.py --config c5proxy [--peak P]
+      the stand-in for BASELINE.json configs[4] (the real model's checkpoint is not available offline): mixed-length segments
+      of <= 30 s, S = T // 12, both heads from raw logits, SIL in the targets, one bfa_align_heads call per step.
+  --peak P / --sigma S (every config): sharpness of the synthetic posteriors, logits = N(0, S) + P * onehot(planted); the line
+      carries `softness` (log-probability per frame of the aligned path, share of utterances at the reference's -1000
+      sentinel, what the fast windows did).  tools/softness.py sweeps it over the call shapes.
+
 Timing protocol: W warm-up steps, then ceil(100 / K) windows of EXACTLY K steps, each bracketed by barrier +
 synchronize on both sides, max over ranks; `value` = frames of all windows / sum of the window times.  Everything that
 ran before the reported windows (warm-up, the first window -- reported separately --, the --settle-ms steps) is counted
@@ -278,7 +285,7 @@ def headline_main(args, rk):
     inflight = max(1, args.inflight if args.inflight is not None else 4)
     nbuf = max(2, inflight)
     # distinct batches so consecutive steps never stream the same 1.1 GB (> the 256 MB Infinity Cache anyway)
-    bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
+    bufs = [synth_batch(B, T, S, C, 1003 + 17 * rank + 1000 * i, dev, peak=args.peak, sigma=args.sigma) for i in range(nbuf)]
     if os.environ.get("BFA_BENCH_SAME_INPUT"):  # (experiment: every utterance reads utterance 0 -> cache-resident rows)
         bufs = [(lp[:1].expand(B, T, C), tk[:1].expand(B, S).contiguous()) for lp, tk in bufs]
     if args.row_pitch:  # A/B: the same log-probs in rows padded to `row_pitch` floats (e.g. 72 = 288 B)
@@ -500,6 +507,7 @@ def headline_main(args, rk):
                 "issue_floor_what": f"insts / ({N_SIMD} SIMDs x {SIMD_CLOCK_HZ / 1e9:g} GHz / 4 cycles per wave64 instruction)",
                 "kernel_over_floor": kernel_ms / floor_ms}
 
+    soft = softness_record(args, au.viterbi_decoder, bufs[(counter[0] - 1) % nbuf], T_len, S_len, res) if rank == 0 else None
     ranks = rk.describe()
     if rank == 0:
         kname = "k_dp4w<2,4,3> (K1 banded Viterbi forward, sliding-window consumer)" if (B, T, S, C) == (4096, 1000, 40, 67) \
@@ -562,6 +570,7 @@ def headline_main(args, rk):
                                        "frac_by_busy_time": (alg_bytes / (busy_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                        if busy_per_launch else None}},
             "cpu_baseline": cpu,
+            "softness": soft,
             "reference_cpu_baseline": _reference_cpu_record(),
             "step": "K1 + K2 + K3: alignment, walk / tuples, confidence pass (core.py:902-937)" if not args.no_confidences
                     else "K1 + K2: alignment, walk / tuples (--no-confidences)",
@@ -573,6 +582,30 @@ def headline_main(args, rk):
             "ranks": ranks,
         }
         print(json.dumps(line))
+
+
+def softness_record(args, vd, buf, T_len, S_len, res, n=64):
+    """How sharp the synthetic posteriors of this run are and what that made the library do: the
+    generator's peak / sigma, the mean log-probability per frame of the aligned path on the prepared emissions, the share of a
+    sample whose path ends at the reference's -1000 sentinel (forced_alignment.py:23,656-682), and the window counters of the
+    last call (bfa_call_counters)."""
+    try:
+        lp, tk = buf
+        n = min(n, lp.shape[0])
+        m = vd.prepare_emissions(lp[:n], tk[:n], T_len[:n], S_len[:n])
+        fph = res.frame_phonemes[:n].long().clamp(min=0)
+        g = m.gather(2, fph.unsqueeze(-1)).squeeze(-1).double()
+        mask = torch.arange(lp.shape[1], device=lp.device)[None, :] < T_len[:n, None]
+        tot = (g * mask).sum(1)
+        cnt = res.call_counters()
+        return {"peak": args.peak, "sigma": args.sigma, "what": "logits = N(0, sigma) + peak * onehot(planted path)",
+                "path_logp_per_frame": float(tot.sum() / mask.sum()), "sample_share_at_sentinel": float((tot <= -1000.0).double().mean()),
+                "last_call": {k: cnt[k] for k in ("items", "redone_full", "redone_exact", "exact_done", "exact_alive")},
+                "last_call_what": "redone_*: fast windows that gave up (dead / doomed) and were aligned again; exact_done / exact_alive: "
+                                  "items the exact window aligned (reruns + calls routed there at once, BFA_OPT_WINDOW_ROUTING) / of "
+                                  "those above the sentinel"}
+    except Exception as e:  # (a measurement aid, never the reason a bench line is missing)
+        return {"peak": args.peak, "sigma": args.sigma, "error": repr(e)}
 
 
 def cpu_baseline_leg(args, bufs, step, B, T, S, C, blank, sil):
@@ -720,7 +753,7 @@ def c4_main(args, rk):
         lps, tks = [], []
         for i in range(0, len(ch), 512):
             sub = ch[i:i + 512]
-            lp, tk = c4_utterances(sub, T[sub], S[sub], C, seed, dev, Tpad=Tp, Spad=Sp)
+            lp, tk = c4_utterances(sub, T[sub], S[sub], C, seed, dev, Tpad=Tp, Spad=Sp, peak=args.peak, sigma=args.sigma)
             lps.append(lp)
             tks.append(tk)
         lp = torch.cat(lps, 0) if len(lps) > 1 else lps[0]
@@ -895,7 +928,7 @@ def c4_parity_sample(args, T, S, out, cap, dev, C, seed):
     w = 0.0
     for i in range(0, len(sample), 64):
         sub = sample[i:i + 64]
-        lp, tk = c4_utterances(sub, T[sub], S[sub], C, seed, dev)
+        lp, tk = c4_utterances(sub, T[sub], S[sub], C, seed, dev, peak=args.peak, sigma=args.sigma)
         cs = input_checksum(lp, T[sub]).cpu().numpy()
         lp_h, tk_h = lp.cpu().numpy(), tk.cpu().numpy()
         w0 = time.perf_counter()
@@ -933,7 +966,8 @@ def realtext_main(args, rk):
     K = args.steps
     nfl = max(1, args.inflight if args.inflight is not None else 3)
     nbuf = max(2, nfl)
-    bufs = [synth_realtext(B, T, S, 2003 + 17 * rank + 1000 * i, dev) for i in range(nbuf)]
+    bufs = [synth_realtext(B, T, S, 2003 + 17 * rank + 1000 * i, dev, peak=args.peak, gpeak=max(1.0, args.peak - 2.0), sigma=args.sigma)
+            for i in range(nbuf)]
     T_len = torch.full((B,), T, dtype=torch.int32, device=dev)
     S_len = torch.full((B,), S, dtype=torch.int32, device=dev)
     slots = []
@@ -1100,6 +1134,96 @@ def realtext_parity(args, slot, one, buf, T, S, soft):
                     "decode_alignments -> ensure_target_coverage -> extend_soft_boundaries -> confidences)"}
 
 
+# ---------------------------------------------------------------------------------------------- c5proxy
+def c5proxy_main(args, rk):
+    """`--config c5proxy`: the stand-in for BASELINE.json configs[4] (LJSpeech through the real model -- whose checkpoint the
+    reference downloads at core.py:260-285 and which is not available offline): what `process_segments` hands the path --
+    segments of at most 30 s (T ~ U[300, 1870] frames, README.md:1231), S = T // 12 targets, SIL at the punctuation rate of the
+    reference's committed LJSpeech outputs (2 in 110 phonemes) with planted silences, RAW logits of both heads, mixed lengths
+    in one call, coverage + soft boundaries + confidences behind each head's alignment (core.py:897-937).  One step = ONE
+    bfa_align_heads call over `--batch` utterances per GPU (weak scaling); `--peak` / `--sigma` set the sharpness.  Parity: a
+    stratified sample (incl. the longest utterances) through the oracle's whole chain on rank 0."""
+    from bournemouth_forced_aligner_amd import AlignmentUtils, _lib
+    from bournemouth_forced_aligner_amd.forced_alignment import align_heads
+    from tools.synth import synth_realtext_ragged
+    from tools.softness import parity_heads, stratified
+    dev, rank, world = rk.dev, rk.rank, rk.world
+    B, K = args.batch, args.steps
+    nfl = max(1, args.inflight if args.inflight is not None else 1)
+    xs = synth_realtext_ragged(B, args.tlo, args.thi, args.tok_div, 2004 + 17 * rank, dev, peak=args.peak,
+                               gpeak=max(1.0, args.peak - 2.0), sigma=args.sigma)
+    bufs, Tl, Sl = xs[:4], xs[4].numpy().astype(np.int64), xs[5].numpy().astype(np.int64)
+    xp, xg, tp, tg = bufs
+    Td, Sd = xs[4].to(dev), xs[5].to(dev)
+    slots, streams = [], []
+    for k in range(nfl):
+        ap_, ag_ = AlignmentUtils(blank_id=66, silence_id=0), AlignmentUtils(blank_id=16, silence_id=0)
+        ap_.viterbi_decoder.handle_slot = ag_.viterbi_decoder.handle_slot = k
+        slots.append((ap_, ag_))
+        _lib.set_calls_in_flight(rk.dev.index, k, nfl > 1)
+        streams.append(torch.cuda.Stream(device=dev) if nfl > 1 else None)
+    vd = slots[0][0].viterbi_decoder
+    hints = [vd.class_mask_hint(Tl, Sl, has_sil=True, n_classes=67), vd.class_mask_hint(Tl, Sl, has_sil=True, n_classes=17)]
+    counter, last = [0], [None]
+
+    def one(k):
+        ap_, ag_ = slots[k]
+        (rp, _sp), (rg, _sg) = align_heads([ap_, ag_], [xp, xg], [tp, tg], Td, Sd, class_masks=hints,
+                                           post={"extend": True, "boundary_softness": 3})
+        return rp, rg
+
+    def run_steps(n):
+        for _ in range(n):
+            k = counter[0] % nfl
+            counter[0] += 1
+            if streams[k] is None:
+                last[0] = one(k)
+            else:
+                with torch.cuda.stream(streams[k]):
+                    last[0] = one(k)
+
+    run_steps(max(1, args.warmup))
+    torch.cuda.synchronize()
+    for r in last[0]:
+        assert bool((r.status.cpu() == 0).all()) and bool((r.conf_status.cpu() == 0).all()), "alignment failed on the c5proxy workload"
+    n_windows = max(1, -(-args.min_timed_steps // K))
+    win_t, issue_t = _timed_windows(rk, run_steps, K, n_windows)
+    total_steps = K * n_windows
+    elapsed = float(np.sum(win_t))
+    step_s = elapsed / total_steps
+    frames = int(Tl.sum())
+    nbytes = int(((4 * 67 + 4 * 17 + 4 * 67 + 2 * ((4 * Sl + 1 + 3) // 4) + 2 * 8) * Tl).sum())
+    modes = [r.mode.cpu().numpy() for r in last[0]]
+    parity = None
+    if rank == 0 and args.parity_sample > 0:
+        got = one(0)
+        torch.cuda.synchronize()
+        parity = parity_heads(bufs, Tl, Sl, got, stratified(Tl, max(4, args.parity_sample // 2)))
+    ranks = rk.describe()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "aligned frames/sec (whole node) on ph66 posteriors, C5 proxy (mixed-length segments <= 30 s, both heads "
+                      "from raw logits, SIL in the targets)", "value": world * frames / step_s, "unit": "aligned frames/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"c5proxy: batch={B} per GPU, T~U[{args.tlo},{args.thi}], S=T//{args.tok_div}, SIL at 1/40 of the "
+                                   f"targets with planted 6-30-frame silences, ph66 head (C=67) + group head (C=17) from RAW logits, "
+                                   f"reference-default flags; step = bfa_align_heads with the post-DP stages of both heads; "
+                                   f"{nfl} step(s) in flight; logits N(0,{args.sigma:g}) + {args.peak:g} on the planted class",
+                       "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+            "timing": {"windows": n_windows, "timed_steps_total": total_steps,
+                       "window_ms_per_step": [t / K * 1e3 for t in win_t],
+                       "host_issue_ms_per_step": float(np.sum(issue_t)) / total_steps * 1e3},
+            "frames_per_step": frames,
+            "roofline": {"bound": "hbm", "achieved": nbytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": nbytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole step (K0 row pass + planner + piece / fallback DPs + walks of both heads, post-DP stages)",
+                         "algorithmic_bytes_per_step": nbytes},
+            "softness": {"peak": args.peak, "gpeak": max(1.0, args.peak - 2.0), "sigma": args.sigma},
+            "segmented_share": {"ph66": float((modes[0] == 1).mean()), "groups": float((modes[1] == 1).mean())},
+            "parity": parity, "rccl_ranks_seen": rk.group_record()["rccl_ranks_seen"], "group": rk.group_record(), "ranks": ranks}))
+
+
 # ----------------------------------------------------------------------------------------------- ragged
 def ragged_main(args, rk):
     """Side measurement: throughput on ONE unsorted mixed-length call (prints its own JSON; its parity check against
@@ -1107,7 +1231,7 @@ def ragged_main(args, rk):
     from bournemouth_forced_aligner_amd import AlignmentUtils
     dev, rank = rk.dev, rk.rank
     C, B = args.classes, args.batch
-    lp, tk, T_len, S_len = synth_ragged(B, args.tlo, args.thi, C, 1004 + rank, dev)
+    lp, tk, T_len, S_len = synth_ragged(B, args.tlo, args.thi, C, 1004 + rank, dev, peak=args.peak, sigma=args.sigma, tok_div=args.tok_div)
     au = AlignmentUtils(blank_id=C - 1, silence_id=0)
     au.viterbi_decoder.window_max_frames = args.win_frames or None
     au.viterbi_decoder.window_max_tokens = args.win_tokens or None
@@ -1156,7 +1280,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["headline", "c2", "c4", "realtext"], default="headline",
+    ap.add_argument("--config", choices=["headline", "c2", "c4", "realtext", "c5proxy"], default="headline",
                     help="headline = BASELINE configs[2]; c2 = configs[1] (batch 256, T 600, 20 tokens) through the headline "
                          "path; c4 = configs[3]; realtext = both heads from raw logits with SIL in the targets")
     ap.add_argument("--min-timed-steps", type=int, default=100,
@@ -1204,6 +1328,12 @@ def main():
     ap.add_argument("--parity-sample", type=int, default=None,
                     help="utterances rank 0 checks against the oracle (c4: default 256, stratified; realtext: default 512)")
     ap.add_argument("--dry-run", action="store_true", help="launch + partition + gather plumbing on gloo, no GPU work")
+    ap.add_argument("--peak", type=float, default=9.0,
+                    help="sharpness of the synthetic posteriors: logits = N(0, sigma) + peak * onehot(planted).  9 (every round so "
+                         "far): the aligned path loses ~0.4 per frame after the reference's target boost; 7: ~1.3 (a 1000-frame "
+                         "utterance ends below the reference's -1000 sentinel); 3: ~6")
+    ap.add_argument("--sigma", type=float, default=1.0, help="noise scale of the synthetic logits")
+    ap.add_argument("--tok-div", type=int, default=None, help="--ragged / c5proxy: targets per utterance = frames // this (25; c5proxy: 12)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="N ranks with REAL GPU work on fewer GPUs than ranks (device = LOCAL_RANK %% device_count) over a gloo "
                          "group with the records staged through pinned host memory: correctness of the N > 1 path on one GPU "
@@ -1220,8 +1350,13 @@ def main():
 
     if args.config == "c2":
         args.batch, args.frames, args.tokens = 256, 600, 20
+    if args.config == "c5proxy":   # BASELINE.json configs[4] without the model: segments of <= 30 s, both heads, SIL in the targets
+        if (args.tlo, args.thi) == (200, 3000):
+            args.tlo, args.thi = 300, 1870
+        args.tok_div = args.tok_div or 12
+    args.tok_div = args.tok_div or 25
     if args.parity_sample is None:
-        args.parity_sample = 512 if args.config == "realtext" else 256
+        args.parity_sample = 512 if args.config == "realtext" else (64 if args.config == "c5proxy" else 256)
     rk = Ranks(args, need_group=(args.config == "c4" or args.force_group))
     if args.ragged:
         ragged_main(args, rk)
@@ -1229,6 +1364,8 @@ def main():
         c4_main(args, rk)
     elif args.config == "realtext" and not args.dry_run:
         realtext_main(args, rk)
+    elif args.config == "c5proxy" and not args.dry_run:
+        c5proxy_main(args, rk)
     elif args.dry_run:
         dry_headline(args, rk)
     else:

@@ -222,6 +222,9 @@ struct PostConfArgs {
 #ifndef BFA_STAGE_K
 #define BFA_STAGE_K 4
 #endif
+#ifndef BFA_POST_NW4_MAX_BATCH
+#define BFA_POST_NW4_MAX_BATCH 512
+#endif
 constexpr int STAGE_K = BFA_STAGE_K; // frames staged on either side of a tuple (probes beyond fall back to memory)
 
 template <bool RAW>
@@ -238,9 +241,29 @@ struct StagedProb {
     }
 };
 
-template <bool RAW>
-__global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
+// NW wavefronts per utterance (round 6).  One wave per utterance is a single instruction stream of ~10^5 cycles for a 30-s
+// segment with 150 tuples: in a call of the reference's sixteen utterances the two heads' k_postconf launches were 0.25-0.29 ms
+// of a 1.15-ms call, every SIMD but sixteen idle (profiles/r06_latency_realtext_timeline_b16_after.txt).  With NW = 4 the
+// staging (cells, exponentials), the means, the passes and the confidences are shared out over 256 lanes, the prefix sums of the
+// window layout stay with wave 0, and the wave-level syncs become workgroup barriers.  Full batches keep NW = 1.
+template <bool RAW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
 {
+    __shared__ int s_flag, s_tot, s_m;
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x, wave = (int)(threadIdx.x >> 6);
+    auto post_sync = [&]() { if (NW == 1) bfa::post_sync(); else __syncthreads(); };
+    // does the predicate hold for any tuple of the utterance? (all threads call this)
+    auto any_wg = [&](int x) -> bool {
+        if (NW == 1) return __any(x) != 0;
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        if (x) s_flag = 1;
+        __syncthreads();
+        const bool r = s_flag != 0;
+        __syncthreads();
+        return r;
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     // [seg_cap] doubles | [seg_cap] tuples | 4 x [seg_cap] ints | [cap_cells] floats
     double *smean = (double *)dyn_lds;
@@ -262,21 +285,25 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
             // ---- ensure_target_coverage (default): drop idx == -1 or idx >= S (core.py:488-513)
             const int S = a.S_len[b];
             m = 0;
-            for (int base = 0; base < n; base += 64) {
-                const int i = base + lane;
-                bfa_segment g;
-                bool keep = false;
-                if (i < n) { g = sg[i]; keep = (g.target_idx != -1 && g.target_idx < S); }
-                const unsigned long long km = __ballot(keep);
-                if (keep) st[m + __builtin_popcountll(km & ((1ull << lane) - 1ull))] = g;
-                m += __builtin_popcountll(km);
+            if (wave == 0) {
+                for (int base = 0; base < n; base += 64) {
+                    const int i = base + lane;
+                    bfa_segment g;
+                    bool keep = false;
+                    if (i < n) { g = sg[i]; keep = (g.target_idx != -1 && g.target_idx < S); }
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) st[m + __builtin_popcountll(km & ((1ull << lane) - 1ull))] = g;
+                    m += __builtin_popcountll(km);
+                }
+                if (NW > 1 && lane == 0) s_m = m;
             }
             post_sync();
+            if (NW > 1) m = s_m;
             // stable sort by start (core.py:660); assort output is already ordered, so this is a check
             int unsorted = 0;
-            for (int i = lane; i + 1 < m; i += 64) if (st[i].start > st[i + 1].start) unsorted = 1;
-            if (__any(unsorted)) {
-                if (lane == 0) {
+            for (int i = tid; i + 1 < m; i += NT) if (st[i].start > st[i + 1].start) unsorted = 1;
+            if (any_wg(unsorted)) {
+                if (tid == 0) {
                     for (int i = 1; i < m; ++i) {
                         const bfa_segment key = st[i];
                         int j = i - 1;
@@ -287,7 +314,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                 post_sync();
             }
         } else {
-            for (int i = lane; i < m; i += 64) st[i] = sg[i];
+            for (int i = tid; i < m; i += NT) st[i] = sg[i];
             post_sync();
         }
         const int Tpad = a.Tmax;                      // the soft-boundary stage works on the padded rows (core.py:705)
@@ -304,6 +331,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
         // Tmax + 2 K seg_cap cells.  Returns the number of cells.
         auto assign_windows = [&](int mode, int W) -> int {
             int tot = 0;
+            if (NW > 1 && wave != 0) { __syncthreads(); return s_tot; } // (the running offsets are one wave's)
             for (int base = 0; base < m; base += 64) {
                 const int i = base + lane;
                 int len = 0, lo = 0;
@@ -333,12 +361,13 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                 if (i < m) { off[i] = tot + incl - len; wlo[i] = lo; whi[i] = lo + len; }
                 tot += __shfl(incl, 63);
             }
+            if (NW > 1) { if (lane == 0) s_tot = tot; __syncthreads(); }
             return tot;
         };
         // ---- stage: cell c belongs to the tuple i with off[i] <= c < off[i] + len_i (binary search), frame wlo[i] + (c - off[i])
         auto stage_cells = [&](int total) {
             constexpr int U = 8;
-            for (int c0 = 0; c0 < total; c0 += 64 * U) {
+            for (int c0 = wave * 64 * U; c0 < total; c0 += NT * U) {
                 float x[U];
                 float2 ms[U];
                 int cell[U];
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                 post_sync();
             }
             if (tot > a.cap_cells) { // (overlapping caller-made tuples: nothing is staged)
-                for (int i = lane; i < m; i += 64) whi[i] = wlo[i];
+                for (int i = tid; i < m; i += NT) whi[i] = wlo[i];
                 tot = 0;
             }
             post_sync();
@@ -385,7 +414,8 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
         if (staging) {
             total = assign_windows(0, 0);
             if (total > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
-                for (int i = lane; i < m; i += 64) whi[i] = wlo[i];
+                post_sync();
+                for (int i = tid; i < m; i += NT) whi[i] = wlo[i];
                 total = 0;
             }
             post_sync();
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
         const StagedProb<RAW> pr{lp, sp, off, wlo, whi};
         if (a.do_post && a.extend) {
             // ---- segment means (core.py:709-714): torch's float32 cascade sum of the strided slice, / n in float32
-            for (int i = lane; i < m; i += 64) {
+            for (int i = tid; i < m; i += NT) {
                 const bfa_segment g = st[i];
                 double mean = 0.001;
                 if (g.start < Tpad && g.phoneme < a.C && g.start < g.end) {
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
             int wide = 0;
             if (total > 0) {
                 int anyw = 0;
-                for (int i = lane; i < m; i += 64) {
+                for (int i = tid; i < m; i += NT) {
                     const bfa_segment g = st[i];
                     int fl = 0;
                     const int lo = wlo[i], hi = whi[i];
@@ -444,12 +474,12 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                     wfl[i] = fl;
                     anyw |= fl;
                 }
-                wide = __any(anyw) ? 1 : 0;
+                wide = any_wg(anyw) ? 1 : 0;
                 if (wide) total = restage(1);
             }
             // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
             for (int pass = 1; pass <= 4; ++pass) {
-                for (int i = lane; i < m; i += 64) {
+                for (int i = tid; i < m; i += NT) {
                     const int ph = st[i].phoneme, s = st[i].start, e = st[i].end;
                     if (s >= Tpad || ph >= a.C) continue; // :719,:740,:760,:784
                     const int d = e - s;
@@ -490,17 +520,17 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
             }
         }
         if (a.do_post) {
-            for (int i = lane; i < m; i += 64) sg[i] = st[i];
-            if (lane == 0) a.seg_count[b] = m;
+            for (int i = tid; i < m; i += NT) sg[i] = st[i];
+            if (tid == 0) a.seg_count[b] = m;
         }
         if (a.do_conf) {
             // ---- _calculate_confidences (utils.py:70-113) on the tuples as they are now
             float *cf = a.conf + (int64_t)b * a.seg_cap;
-            for (int i = (m < 0 ? 0 : m) + lane; i < a.seg_cap; i += 64) cf[i] = 0.0f; // the caller's buffer needs no fill ahead of the call
+            for (int i = (m < 0 ? 0 : m) + tid; i < a.seg_cap; i += NT) cf[i] = 0.0f; // the caller's buffer needs no fill ahead of the call
             int bad = 0;
             // does any tuple read a cell that an earlier tuple has written through its 0-dim view?
             int alias = 0;
-            for (int i = lane; i < m; i += 64) {
+            for (int i = tid; i < m; i += NT) {
                 const int ph = st[i].phoneme;
                 const int s = max(0, st[i].start), e = min(Tc, st[i].end);
                 for (int k = 0; k < i; ++k) {
@@ -509,9 +539,9 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                     if (sk == s || (sk >= s && sk < e)) { alias = 1; break; }
                 }
             }
-            alias = __any(alias);
+            alias = any_wg(alias) ? 1 : 0;
             if (!alias) {
-                for (int i = lane; i < m; i += 64) {
+                for (int i = tid; i < m; i += NT) {
                     const int ph = st[i].phoneme;
                     const int s = max(0, st[i].start), e = min(Tc, st[i].end); // :86-87
                     if (s >= Tc || ph < 0 || ph >= a.C) { bad = 1; cf[i] = 0.0f; continue; } // IndexError at :89
@@ -539,9 +569,9 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
                 post_sync();
                 float *mval = sp;
                 uint8_t *mflag = (uint8_t *)(sp + m);
-                for (int i = lane; i < m; i += 64) mflag[i] = 0;
+                for (int i = tid; i < m; i += NT) mflag[i] = 0;
                 post_sync();
-                if (lane == 0) {
+                if (tid == 0) {
                     auto prob = [&](int f, int ph, int upto) -> float {
                         for (int k = upto; k >= 0; --k)
                             if (mflag[k] && st[k].phoneme == ph && max(0, st[k].start) == f) return mval[k];
@@ -573,8 +603,8 @@ __global__ __launch_bounds__(64) void k_postconf(PostConfArgs a)
             } else {
                 bad = 1;
             }
-            bad = __any(bad);
-            if (lane == 0 && a.status) a.status[b] = bad ? BFA_ITEM_BAD_TOKEN : BFA_ITEM_OK;
+            bad = any_wg(bad) ? 1 : 0;
+            if (tid == 0 && a.status) a.status[b] = bad ? BFA_ITEM_BAD_TOKEN : BFA_ITEM_OK;
         }
     }
 }
@@ -632,11 +662,21 @@ extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t 
     a.S_len = S_len; a.segs = segs; a.seg_cap = seg_cap; a.seg_count = seg_count; a.do_post = do_post; a.extend = extend;
     a.do_conf = do_conf; a.th1 = th1; a.th2 = th2; a.T_rows = T_rows; a.conf = conf; a.status = status; a.cap_cells = cap_cells;
     if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)k_postconf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)k_postconf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_postconf<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)k_postconf<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int grid = B < 65536 ? B : 65536; // (fewer workgroups were measured: profiles/r05_postconf_clip_grid_ab.txt)
-    if (row_stats) hipLaunchKernelGGL(k_postconf<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL(k_postconf<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
+    // four waves per utterance while that still leaves the machine room (256 CUs x ~2 such workgroups), one otherwise
+    if (B <= BFA_POST_NW4_MAX_BATCH) {
+        if (lds > 48 * 1024) {
+            (void)hipFuncSetAttribute((const void *)k_postconf<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)k_postconf<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (row_stats) hipLaunchKernelGGL((k_postconf<true, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream_, a);
+        else hipLaunchKernelGGL((k_postconf<false, 4>), dim3(grid), dim3(256), lds, (hipStream_t)stream_, a);
+        return (int)hipGetLastError();
+    }
+    if (row_stats) hipLaunchKernelGGL((k_postconf<true, 1>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL((k_postconf<false, 1>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }

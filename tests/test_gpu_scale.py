@@ -239,3 +239,18 @@ def test_batches_in_flight_helper_matches_plain_calls(gpu_device):
         assert np.array_equal(np.where(keep[:, :, None], r.segs.cpu().numpy(), 0), np.where(keep[:, :, None], segs, 0))
         assert np.array_equal(r.frame_phonemes.cpu().numpy(), fph)
         assert np.array_equal(np.where(keep, cf.cpu().numpy().view(np.int32), 0), np.where(keep, rcf.view(np.int32), 0))
+
+
+def test_bench_c5proxy_mode(gpu_device):
+    """`bench.py --config c5proxy --peak 5` at reduced batch: mixed-length segments up to 30 s, both heads from raw logits, SIL in
+    the targets, posteriors soft enough that the silence anchoring mostly fails and long utterances end at the sentinel; the
+    sampled utterances (incl. the longest) against the oracle's whole chain."""
+    out = _bench_json(["--config", "c5proxy", "--batch", "96", "--steps", "2", "--warmup", "1", "--min-timed-steps", "2",
+                       "--peak", "5", "--parity-sample", "48"])
+    p = out["parity"]
+    assert p["utterances"] >= 24 and p["mismatching_utterances"] == 0 and p["confidence_beyond_1e-4"] == 0
+    assert out["value"] > 0 and out["softness"]["peak"] == 5.0 and out["frames_per_step"] > 96 * 300
+    out = _bench_json(["--steps", "3", "--warmup", "1", "--no-cpu", "--settle-ms", "0", "--min-timed-steps", "3", "--batch", "2048",
+                       "--peak", "6"])
+    s = out["softness"]
+    assert s["sample_share_at_sentinel"] > 0.9 and s["last_call"]["exact_done"] == 2048, s

@@ -61,7 +61,7 @@ def c4_lengths(n_total, seed=1004, Tlo=200, Thi=3000):
     return T, S
 
 
-def c4_utterances(gidx, T_len, S_len, C, seed, device, Tpad=None, Spad=None, peak=9.0):
+def c4_utterances(gidx, T_len, S_len, C, seed, device, Tpad=None, Spad=None, peak=9.0, sigma=1.0):
     """Posteriors of the utterances with GLOBAL indices `gidx` (lengths T_len / S_len from c4_lengths), padded to
     [n, Tpad, C] / [n, Spad].  Planted path: tokens uniform on 1..C-2 (no SIL, no blank), random monotone segmentation
     with >= 2 frames per token, logits = N(0,1) + peak * onehot(planted), log_probs = log_softmax(logits); rows beyond
@@ -101,6 +101,8 @@ def c4_utterances(gidx, T_len, S_len, C, seed, device, Tpad=None, Spad=None, pea
     u2 = _u01(mix64(_base(seed, _TAG_N2) + key))
     logits = (torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)).to(torch.float32)
     del key, u1, u2
+    if sigma != 1.0:
+        logits *= sigma
     logits.scatter_add_(2, planted.unsqueeze(-1), torch.full((n, Tpad, 1), peak, device=device))
     lp = torch.log_softmax(logits, dim=-1)
     return lp, toks.to(torch.int32)
