@@ -37,13 +37,13 @@ __global__ __launch_bounds__(256) void k_plan(AlignArgs a)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid >> 4, sub = gid & 15;
-    // counters[] are zeroed by a memset node ahead of this kernel; one item slot per utterance, the
-    // segmented planner appends more
+    // One item slot per utterance; the segmented planner appends more.  The counters are zeroed HERE: nothing in this kernel
+    // touches them (round 6: the candidates of the silence-anchored mode are marked in ucand[], not appended to a list through
+    // an atomic counter), the first atomics on them belong to later kernels -- so no call needs a memset dispatch ahead of its
+    // first kernel (until now the silence-anchored mode did: one 64-byte fill per head on a critical path of ~10 short launches).
     if (gid == 0) {
         a.counters[0] = a.B;
-        // without the segmented mode nobody touches counters[1] during planning, and the others are first used by
-        // later kernels: the planner zeroes them itself and the launcher skips its memset
-        if (a.p.win_mask & 0x80000000u) { for (int k = 1; k < 16; ++k) a.counters[k] = 0; }
+        for (int k = 1; k < 16; ++k) a.counters[k] = 0;
     }
     if (b >= a.B) return; // whole 16-lane groups
     plan_utterance(a, b, sub);
@@ -356,8 +356,6 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
         return (int)hipGetLastError();
     }
-    if (seg_possible) (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
-    else a.p.win_mask |= 0x80000000u; // k_plan zeroes the counters (see there)
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
@@ -431,8 +429,7 @@ extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
     const AlignArgs &a = *args;
-    (void)hipMemsetAsync(a.counters, 0, 16 * sizeof(int32_t), stream);
-    hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a); // (zeroes the counters itself)
     int done = 0;
     if (a.C <= 32) done = bfa_launch_prepare_nk2(&a, out, oB, oT, stream);
     else if (a.C <= 80) done = bfa_launch_prepare_nk5(&a, out, oB, oT, stream);

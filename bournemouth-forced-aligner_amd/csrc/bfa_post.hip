@@ -391,132 +391,129 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                 }
             }
         };
-        // the widest reach whose cells fit the LDS (a probe beyond it reads memory), staged
-        auto restage = [&](int mode) -> int {
-            post_sync();
-            int W = 1 << 20, tot = 0;
-            for (;;) {
-                tot = assign_windows(mode, W);
-                if (tot <= a.cap_cells || W <= 1) break;
-                W = (W > 256) ? 256 : (W >> 1);
-                post_sync();
-            }
-            if (tot > a.cap_cells) { // (overlapping caller-made tuples: nothing is staged)
-                for (int i = tid; i < m; i += NT) whi[i] = wlo[i];
-                tot = 0;
-            }
-            post_sync();
-            stage_cells(tot);
-            post_sync();
-            return tot;
-        };
-        int total = 0;
-        if (staging) {
-            total = assign_windows(0, 0);
-            if (total > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
-                post_sync();
-                for (int i = tid; i < m; i += NT) whi[i] = wlo[i];
-                total = 0;
-            }
-            post_sync();
-            stage_cells(total);
-            post_sync();
-        }
         const StagedProb<RAW> pr{lp, sp, off, wlo, whi};
-        if (a.do_post && a.extend) {
-            // ---- segment means (core.py:709-714): torch's float32 cascade sum of the strided slice, / n in float32
-            for (int i = tid; i < m; i += NT) {
-                const bfa_segment g = st[i];
-                double mean = 0.001;
-                if (g.start < Tpad && g.phoneme < a.C && g.start < g.end) {
-                    const int ee = g.end > Tpad ? Tpad : g.end;
-                    const int n = ee - g.start;
-                    const float sum = cascade_sum_f32(n, [&](int e) -> float { return pr.at(i, g.start + e, g.phoneme); });
-                    mean = (double)(sum / (float)n);
+        const bool ext = a.do_post && a.extend;
+        int total = 0, wide = 0;
+        // Three rounds, ONE copy of the staging code (as a helper used from three places it was inlined three times: 150 vector
+        // registers instead of 101, three waves per SIMD instead of four, the real-text step 7 % slower on one box --
+        // profiles/r06_vs_r05.txt).  Round 0: windows of +-K frames, then the means and the wide test; round 1 (only when a walk
+        // can leave its window): windows that reach to the left, then passes 1-3; round 2: to the right, then pass 4.
+#pragma unroll 1
+        for (int round = 0; round < 3; ++round) {
+            if (staging && (round == 0 || wide)) {
+                if (round) post_sync();
+                int W = 1 << 20, tot = 0;
+                for (;;) { // the widest reach whose cells fit the LDS (a probe beyond it reads memory)
+                    tot = assign_windows(round, W);
+                    if (tot <= a.cap_cells || W <= 1 || round == 0) break;
+                    W = (W > 256) ? 256 : (W >> 1);
+                    post_sync();
                 }
-                smean[i] = mean;
+                if (tot > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
+                    post_sync();
+                    for (int i = tid; i < m; i += NT) whi[i] = wlo[i];
+                    tot = 0;
+                }
+                total = tot;
+                post_sync();
+                stage_cells(total);
+                post_sync();
             }
-            post_sync();
-            // ---- Can a walk of the passes below leave its tuple's staged window?  Only if every staged margin cell on that side
-            // is at or above the smallest threshold any pass compares it with (the walks stop at the first cell below theirs) and
-            // the window does not already reach the neighbour.  On sharp posteriors no tuple qualifies and this costs 2 K LDS
-            // reads per tuple.  On soft ones (logits N(0,1) + 3 on the planted class: every class keeps ~1e-2, above both
-            // thresholds) EVERY walk runs to its limit -- through memory that was one dependent 64-byte-sector read, a row
-            // statistics read and a float64 exponential per frame and lane: 12.5 ms per head on the C5 proxy against 0.8 ms on
-            // sharp posteriors (profiles/r06_softness_before.jsonl).  Such tuples get windows that reach as far as their passes
-            // can (the gap to the neighbouring tuple): once to the LEFT for passes 1-3, once to the RIGHT -- from the starts as
-            // pass 3 leaves them -- for pass 4 and the confidences, so that either round needs no more cells than the first (a
-            // gap is staged for one neighbour at a time); the cells of the earlier rounds come from the L2, and the walks run at
-            // LDS speed.  The result does not depend on any of this (StagedProb::at).
-            int wide = 0;
-            if (total > 0) {
-                int anyw = 0;
+            if (!ext) break;
+            if (round == 0) {
+                // ---- segment means (core.py:709-714): torch's float32 cascade sum of the strided slice, / n in float32
                 for (int i = tid; i < m; i += NT) {
                     const bfa_segment g = st[i];
-                    int fl = 0;
-                    const int lo = wlo[i], hi = whi[i];
-                    if (hi > lo) {
-                        const int s0 = max(0, g.start), e1 = max(min(a.Tmax, g.end), s0 + 1);
-                        double tmin = smean[i] * th1; if (tmin > th1) tmin = th1; if (th2 < tmin) tmin = th2;
-                        const int limL = (i > 0) ? min(s0, max(0, st[i - 1].end)) : 0;
-                        const int limR = (i + 1 < m) ? max(e1, min(a.Tmax, st[i + 1].start)) : a.Tmax;
-                        if (lo > limL && s0 > lo) {
-                            bool all = true;
-                            for (int f = lo; f < s0; ++f) all = all && ((double)sp[off[i] + (f - lo)] >= tmin);
-                            if (all) fl |= 1;
-                        }
-                        if (hi < limR && hi > e1) {
-                            bool all = true;
-                            for (int f = e1; f < hi; ++f) all = all && ((double)sp[off[i] + (f - lo)] >= tmin);
-                            if (all) fl |= 2;
-                        }
+                    double mean = 0.001;
+                    if (g.start < Tpad && g.phoneme < a.C && g.start < g.end) {
+                        const int ee = g.end > Tpad ? Tpad : g.end;
+                        const int n = ee - g.start;
+                        const float sum = cascade_sum_f32(n, [&](int e) -> float { return pr.at(i, g.start + e, g.phoneme); });
+                        mean = (double)(sum / (float)n);
                     }
-                    wfl[i] = fl;
-                    anyw |= fl;
-                }
-                wide = any_wg(anyw) ? 1 : 0;
-                if (wide) total = restage(1);
-            }
-            // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
-            for (int pass = 1; pass <= 4; ++pass) {
-                for (int i = tid; i < m; i += NT) {
-                    const int ph = st[i].phoneme, s = st[i].start, e = st[i].end;
-                    if (s >= Tpad || ph >= a.C) continue; // :719,:740,:760,:784
-                    const int d = e - s;
-                    if (pass == 1) { // :717-735
-                        int min_start = (int)((double)s - (double)d * 10.0);
-                        if (min_start < 0) min_start = 0;
-                        if (i > 0) { int v = st[i - 1].end + 10; if (v > s) v = s; if (v > min_start) min_start = v; }
-                        double thr = smean[i] * th1; if (thr > th1) thr = th1;
-                        int ns = s;
-                        for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= thr) ns = f; else break; }
-                        st[i].start = ns;
-                    } else if (pass == 2) { // :738-755
-                        int max_end = (int)((double)e + (double)d * 10.0);
-                        if (max_end > Tpad) max_end = Tpad;
-                        if (i + 1 < m) { int v = st[i + 1].start - 10; if (v > e) v = e; if (v < max_end) max_end = v; }
-                        double thr = smean[i] * th1; if (thr > th1) thr = th1;
-                        int ne = e;
-                        for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= thr) ne = f + 1; else break; }
-                        st[i].end = ne;
-                    } else if (pass == 3) { // :758-778
-                        int min_start = 0;
-                        if (i > 0) min_start = st[i - 1].end;
-                        if (s <= min_start) continue;
-                        int ns = s;
-                        for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= th2) ns = f; else break; }
-                        st[i].start = ns;
-                    } else { // :782-805
-                        int max_end = (int)((double)e + (double)d * 10.0);
-                        if (max_end > Tpad) max_end = Tpad;
-                        if (i + 1 < m) { const int v = st[i + 1].start; if (v < max_end) max_end = v; }
-                        int ne = e;
-                        for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= th2) ne = f + 1; else break; }
-                        st[i].end = ne;
-                    }
+                    smean[i] = mean;
                 }
                 post_sync();
-                if (pass == 3 && wide) total = restage(2);
+                // ---- Can a walk of the passes below leave its tuple's staged window?  Only if every staged margin cell on that side
+                // is at or above the smallest threshold any pass compares it with (the walks stop at the first cell below theirs) and
+                // the window does not already reach the neighbour.  On sharp posteriors no tuple qualifies and this costs 2 K LDS
+                // reads per tuple.  On soft ones (logits N(0,1) + 3 on the planted class: every class keeps ~1e-2, above both
+                // thresholds) EVERY walk runs to its limit -- through memory that was one dependent 64-byte-sector read, a row
+                // statistics read and a float64 exponential per frame and lane: 12.5 ms per head on the C5 proxy against 0.8 ms on
+                // sharp posteriors (profiles/r06_softness_before.jsonl).  Such tuples get windows that reach as far as their passes
+                // can (the gap to the neighbouring tuple): once to the LEFT for passes 1-3, once to the RIGHT -- from the starts as
+                // pass 3 leaves them -- for pass 4 and the confidences, so that either round needs no more cells than the first (a
+                // gap is staged for one neighbour at a time); the cells of the earlier rounds come from the L2, and the walks run at
+                // LDS speed.  The result does not depend on any of this (StagedProb::at).
+                if (total > 0) {
+                    int anyw = 0;
+                    for (int i = tid; i < m; i += NT) {
+                        const bfa_segment g = st[i];
+                        int fl = 0;
+                        const int lo = wlo[i], hi = whi[i];
+                        if (hi > lo) {
+                            const int s0 = max(0, g.start), e1 = max(min(a.Tmax, g.end), s0 + 1);
+                            double tmin = smean[i] * th1; if (tmin > th1) tmin = th1; if (th2 < tmin) tmin = th2;
+                            const int limL = (i > 0) ? min(s0, max(0, st[i - 1].end)) : 0;
+                            const int limR = (i + 1 < m) ? max(e1, min(a.Tmax, st[i + 1].start)) : a.Tmax;
+                            if (lo > limL && s0 > lo) {
+                                bool all = true;
+                                for (int f = lo; f < s0; ++f) all = all && ((double)sp[off[i] + (f - lo)] >= tmin);
+                                if (all) fl |= 1;
+                            }
+                            if (hi < limR && hi > e1) {
+                                bool all = true;
+                                for (int f = e1; f < hi; ++f) all = all && ((double)sp[off[i] + (f - lo)] >= tmin);
+                                if (all) fl |= 2;
+                            }
+                        }
+                        wfl[i] = fl;
+                        anyw |= fl;
+                    }
+                    wide = any_wg(anyw) ? 1 : 0;
+                }
+            } else {
+                // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
+                const int p_last = round == 1 ? 3 : 4;
+                for (int pass = round == 1 ? 1 : 4; pass <= p_last; ++pass) {
+                    for (int i = tid; i < m; i += NT) {
+                        const int ph = st[i].phoneme, s = st[i].start, e = st[i].end;
+                        if (s >= Tpad || ph >= a.C) continue; // :719,:740,:760,:784
+                        const int d = e - s;
+                        if (pass == 1) { // :717-735
+                            int min_start = (int)((double)s - (double)d * 10.0);
+                            if (min_start < 0) min_start = 0;
+                            if (i > 0) { int v = st[i - 1].end + 10; if (v > s) v = s; if (v > min_start) min_start = v; }
+                            double thr = smean[i] * th1; if (thr > th1) thr = th1;
+                            int ns = s;
+                            for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= thr) ns = f; else break; }
+                            st[i].start = ns;
+                        } else if (pass == 2) { // :738-755
+                            int max_end = (int)((double)e + (double)d * 10.0);
+                            if (max_end > Tpad) max_end = Tpad;
+                            if (i + 1 < m) { int v = st[i + 1].start - 10; if (v > e) v = e; if (v < max_end) max_end = v; }
+                            double thr = smean[i] * th1; if (thr > th1) thr = th1;
+                            int ne = e;
+                            for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= thr) ne = f + 1; else break; }
+                            st[i].end = ne;
+                        } else if (pass == 3) { // :758-778
+                            int min_start = 0;
+                            if (i > 0) min_start = st[i - 1].end;
+                            if (s <= min_start) continue;
+                            int ns = s;
+                            for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= th2) ns = f; else break; }
+                            st[i].start = ns;
+                        } else { // :782-805
+                            int max_end = (int)((double)e + (double)d * 10.0);
+                            if (max_end > Tpad) max_end = Tpad;
+                            if (i + 1 < m) { const int v = st[i + 1].start; if (v < max_end) max_end = v; }
+                            int ne = e;
+                            for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= th2) ne = f + 1; else break; }
+                            st[i].end = ne;
+                        }
+                    }
+                    post_sync();
+                }
             }
         }
         if (a.do_post) {

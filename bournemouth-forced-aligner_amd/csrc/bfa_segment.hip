@@ -27,11 +27,12 @@ __global__ __launch_bounds__(64) void k_silprob(AlignArgs a)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const DevParams &p = a.p;
-    const int n_cand = a.counters[1];
+    const int n_cand = a.B; // (candidates are marked in ucand[]: no list, no counter -- see k_plan)
     const int nchunk = (a.Tmax + 63) / 64;
     const int sil_k = p.sil >> 4, sil_j = p.sil & 15;
-    for (int u = blockIdx.x; u < n_cand * nchunk; u += gridDim.x) {
-        const int b = a.cand[u / nchunk];
+    for (int64_t u = blockIdx.x; u < (int64_t)n_cand * nchunk; u += gridDim.x) {
+        const int b = (int)(u / nchunk);
+        if (!a.ucand[b]) continue;
         const int t0 = (u % nchunk) * 64;
         const int T = a.uT[b];
         if (t0 >= T) continue;
@@ -595,9 +596,8 @@ __global__ __launch_bounds__(64) void k_plan_seg(AlignArgs a, int lds_frames, in
     const int lane = threadIdx.x & 63;
     // (wave priority 2 / 3 -- the DP consumers that run beside a planner are at 3 -- measured: real text one call at a time
     // 1.709 -> 1.744 / 1.741 ms, profiles/r05_plan_prio_ab.txt)
-    const int n_cand = a.counters[1];
-    for (int ci = blockIdx.x; ci < n_cand; ci += gridDim.x) {
-        const int b = a.cand[ci];
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if (!a.ucand[b]) continue; // (wave-uniform: one utterance per wavefront)
         const int T = a.uT[b], S = a.uS[b];
         const float *ps = a.psil + (int64_t)b * a.Tmax;
         // budget of the cooperative path: T / min_k + 1 silence runs (min_k = anchors, or 3 on the S > 200 retry) -- real

@@ -176,6 +176,15 @@ class LazyRowDicts(collections.abc.Sequence):
         return self._one(b % self._n if self._n else 0)
 
     def tolist(self):
+        if all(d is None for d in self._dicts):   # nothing looked at yet: every head in one numpy pass, one dict literal per utterance
+            keys = list(self._heads)
+            cols = [self._heads[k].tolist() for k in keys]
+            if len(keys) == 2:
+                k0, k1 = keys
+                self._dicts = [{k0: x, k1: y} for x, y in zip(cols[0], cols[1])]
+            else:
+                self._dicts = [dict(zip(keys, rows)) for rows in zip(*cols)]
+            return list(self._dicts)
         for v in self._heads.values():
             v.tolist()  # every row of a head in one numpy pass
         return [self._one(b) for b in range(self._n)]

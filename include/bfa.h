@@ -158,7 +158,7 @@ size_t bfa_workspace_bytes(int B, int Tmax, int Smax, int C, const bfa_params *p
  * pieces); [2] sliding-window items that gave up (dead or doomed at the reference's -1000 sentinel) and were redone with the
  * full layout; [3] the same, redone with the exact window; standard mode: [4] items the exact rerun kernels aligned (those
  * of [3] plus the ones BFA_OPT_WINDOW_ROUTING handed over at once), [5] how many of them ended above the sentinel;
- * silence-anchored mode: [1] candidate utterances, [4..15] piece counts per length bucket.  Not on any hot path. */
+ * silence-anchored mode: [4..15] piece counts per length bucket.  Not on any hot path. */
 int bfa_call_counters(bfa_handle h, const void *workspace, int B, int Tmax, int Smax, int C, const bfa_params *p,
                       int32_t *out_host, void *stream);
 
