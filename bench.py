@@ -318,6 +318,12 @@ def headline_main(args, rk):
     au = aus[0]
     lib = _lib.lib()
     hs = [_lib.handle(rk.dev.index, k) for k in range(len(aus))]
+    if os.environ.get("BFA_BENCH_PRECREATE"):  # (A/B: the handles' streams created up front, as until round 5)
+        for k in range(len(aus)):
+            _lib.check(lib.bfa_set_option(hs[k], _lib.OPT_PRECREATE_STREAMS, int(os.environ["BFA_BENCH_PRECREATE"])), hs[k], "bfa_set_option")
+    if os.environ.get("BFA_BENCH_ROUTING"):  # (A/B: BFA_OPT_WINDOW_ROUTING of every handle in flight)
+        for k in range(len(aus)):
+            _lib.set_window_routing(rk.dev.index, k, int(os.environ["BFA_BENCH_ROUTING"]))
     # the lengths are known on the host (constant here), and the synthetic targets never contain SIL:
     # tell the library which K1 register class occurs so that it does not launch the empty ones
     hint = au.viterbi_decoder.class_mask_hint([T] * B, [S] * B, has_sil=False, n_classes=(None if args.no_window else C))

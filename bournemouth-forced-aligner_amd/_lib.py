@@ -14,6 +14,7 @@ BFA_ERR_WORKSPACE_TOO_SMALL, BFA_ERR_UNSUPPORTED = -4, -5
 ITEM_OK, ITEM_TOO_SHORT, ITEM_BAD_TOKEN, ITEM_TOO_LARGE, ITEM_SEG_OVERFLOW, ITEM_BAD_HINT = 0, 1, 2, 3, 4, 5
 HINT_NO_SILENCE_TARGETS = 1 << 16
 HINT_UNIFORM_LENGTHS = 1 << 17
+OPT_PRECREATE_STREAMS = 4  # bfa_set_option: create the handle's auxiliary / head streams now instead of at first need
 OPT_WIDE_ANY_MAX_BATCH = 3  # bfa_set_option: silence-anchored calls up to this many utterances take the wide classes as one launch
 OPT_WINDOW_ROUTING = 2  # bfa_set_option: 0 fast window first always, 1 by the handle's history (default), 2 exact window first always
 OPT_CALLS_IN_FLIGHT = 1  # bfa_set_option: the caller keeps several bfa_align_heads calls in flight (BatchesInFlight)
@@ -138,6 +139,18 @@ def set_calls_in_flight(device_index, slot, on):
     (one handle / stream each), see include/bfa.h."""
     h = handle(device_index, slot)
     check(lib().bfa_set_option(h, OPT_CALLS_IN_FLIGHT, 1 if on else 0), h, "bfa_set_option")
+    # (no precreate_streams here: three bfa_align_heads calls in flight measured SLOWER with the auxiliary streams in existence,
+    # 1.53 against 1.43 ms per real-text step on one box -- the mapping of streams onto hardware queues is the runtime's)
+
+
+def precreate_streams(device_index, slot, which=1):
+    """BFA_OPT_PRECREATE_STREAMS: create the handle's auxiliary streams (1), head streams (2) or both (3) now.  A handle creates
+    them when a call first needs them (a fresh process then aligns its first chunk 22 ms sooner); callers that keep several
+    calls in flight on several handles create them up front: with them in existence the runtime spreads the callers' own
+    streams over its hardware queues differently, and four headline batches in flight run 6 % faster (0.40 against 0.43 ms per
+    step on one box, profiles/r06_precreate_ab.txt)."""
+    h = handle(device_index, slot)
+    check(lib().bfa_set_option(h, OPT_PRECREATE_STREAMS, int(which)), h, "bfa_set_option")
 
 
 def set_window_routing(device_index, slot, value):

@@ -582,6 +582,12 @@ int bfa_set_option(bfa_handle h, int option, int value)
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     if (option == BFA_OPT_CALLS_IN_FLIGHT) { h->calls_in_flight = value != 0; return BFA_OK; }
     if (option == BFA_OPT_WIDE_ANY_MAX_BATCH) { h->wide_any_max = value; return BFA_OK; }
+    if (option == BFA_OPT_PRECREATE_STREAMS) { // (the streams a handle otherwise creates when a call first needs them)
+        DeviceGuard guard(h);
+        if (value & 1) (void)ensure_aux((void *)h);
+        if (value & 2) ensure_head_streams(h);
+        return BFA_OK;
+    }
     if (option == BFA_OPT_WINDOW_ROUTING) {
         if (value < 0 || value > 2) return fail(h, BFA_ERR_INVALID_ARGUMENT, "window routing: 0 never, 1 by history, 2 always");
         h->routing = value; h->route_state[0] = h->route_state[1] = 0;

@@ -28,6 +28,11 @@ class BatchesInFlight:
             d.viterbi_decoder.handle_slot = first_handle_slot + k
         # one batch in flight: the caller's current stream, exactly the plain call
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n)] if n > 1 else [None]
+        if n > 1:  # several calls in flight: the handles' auxiliary streams up front (_lib.precreate_streams says why)
+            from . import _lib
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            for d in self.decoders:
+                _lib.precreate_streams(idx, d.viterbi_decoder.handle_slot)
         self._next = 0
 
     @property

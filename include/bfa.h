@@ -280,10 +280,15 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
  *       hand it their utterance slots (standard-mode fallbacks) as well instead of a kernel per class -- on an empty machine
  *       the launches are the cost, on a full one the registers of the widest class are.  < 0: a kernel per class and item
  *       kind for both (the layout of rounds 2-5, kept for A/B).
+ *   BFA_OPT_PRECREATE_STREAMS  value bit 0: create the handle's auxiliary streams now, bit 1: the streams of bfa_align_heads.  A
+ *       handle creates them when a call first needs them (bfa_create 22 ms -> 0.02 ms); a caller that keeps several calls in
+ *       flight on several handles wants them up front: their existence changes how the runtime spreads the CALLER's streams
+ *       over its hardware queues (four headline batches in flight: 0.40 against 0.43 ms per step).
  */
 #define BFA_OPT_CALLS_IN_FLIGHT 1
 #define BFA_OPT_WINDOW_ROUTING 2
 #define BFA_OPT_WIDE_ANY_MAX_BATCH 3
+#define BFA_OPT_PRECREATE_STREAMS 4
 int bfa_set_option(bfa_handle h, int option, int value);
 
 /*
