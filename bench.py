@@ -253,7 +253,7 @@ def measured_copy_peak(dev, lib, h, nbytes=1 << 30, reps=12):
 
 def k1_valu_from_pmc(kernel_prefix="k_dp4w<2, 4, 3"):
     """SQ_INSTS_VALU of the headline K1 per launch from the newest committed PMC summary (tools/pmc.sh format)."""
-    for name in ("r05_headline_pmc.txt", "r04_headline_pmc.txt"):
+    for name in ("r06_headline_pmc.txt", "r05_headline_pmc.txt", "r04_headline_pmc.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -497,7 +497,7 @@ def headline_main(args, rk):
     # HBM bytes of one K1 launch from the PMC passes of tools/profile.sh (committed under profiles/), if it was
     # taken on this workload; FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes
     traffic, tfile = None, None
-    for name in ("r05_k1_traffic.json", "r04_k1_traffic.json", "r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
+    for name in ("r06_k1_traffic.json", "r05_k1_traffic.json", "r04_k1_traffic.json", "r03_k1_traffic.json", "r02_k1_traffic.json", "r01_k1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and (B, T, S, C) == (4096, 1000, 40, 67) and not args.row_pitch:
             traffic, tfile = json.load(open(tpath))["traffic_bytes_per_launch"], name
