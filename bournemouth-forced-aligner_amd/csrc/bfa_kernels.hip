@@ -253,11 +253,11 @@ struct CallPlan {
     int mode;            // 0 reference-default flags without silence anchoring, 1 with, 2 other flags (no fused preparation)
     unsigned mask;       // class kernels that may find items: bits 0-6 full layouts, 8-15 fast windows, 20-27 exact windows
     unsigned wmask, wall, xmask;
-    bool hinted, seg_possible, one_ok, use_mix;
+    bool hinted, seg_possible, one_ok, use_mix, seg_mix;
     int rw1;
 };
 
-static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frames)
+static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frames, int wide_any_max = 256)
 {
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
     const int Lmax = 4 * Smax + 1;
@@ -304,10 +304,28 @@ static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frame
         const unsigned narrow_x = hinted ? (wall & (((unsigned)p.class_mask >> 20) | ((unsigned)p.class_mask >> 8)) & 0xfu) : (wall & 0xfu);
         xmask |= narrow_x | XWIN_MIX;
     }
+    // Silence-anchored mixed-length calls (round 6): an utterance whose anchoring FAILS is aligned in the standard mode
+    // (forced_alignment.py:131-141) -- with soft posteriors that is every utterance of the call (no window average reaches 0.9),
+    // and until now each took the full state layout of its class, one kernel per class (C5 proxy: 8.3 ms at peak 3 against 5.1
+    // at peak 9, profiles/r06_c5proxy_p*.json).  k_plan marks the banded stride >= 3 fallbacks of the window classes Rw <= 4 as
+    // exact-window items (the planner drops the slot when the anchoring succeeds) and k_mix aligns and walks them, longest
+    // first, exactly as in a standard-mode mixed call.  The fast window stays out of this mode (wmask = 0).
+    bool seg_mix = false;
+    // (full batches only: a small call keeps its fallbacks in the one wide launch, k_dp5_any -- behind it on the caller's stream
+    // k_mix doubled the DP phase of the reference's sixteen-utterance chunk, profiles/r06_segmix_ab.txt)
+    if (mode == 1 && (C == 67 || C == 17) && Lmax > 60 && p.min_logp <= 0.0f && B > wide_any_max &&
+        !(p.class_mask & BFA_HINT_UNIFORM_LENGTHS) && frames) {
+        unsigned w4 = 0xfu;
+        const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
+        for (int rw = 4; rw >= 1; --rw) if (top > 0 && rw > top) w4 &= ~(1u << (rw - 1));
+        xmask = w4 | XWIN_MIX;
+        seg_mix = w4 != 0u;
+        if (!seg_mix) xmask = 0;
+    }
     mask |= (xmask & 0xafu) << 20;
     CallPlan c;
     c.mode = mode; c.mask = mask; c.wmask = wmask; c.wall = wall; c.xmask = xmask; c.hinted = hinted;
-    c.seg_possible = seg_possible; c.one_ok = one_ok && (xmask & 0xafu) == 0; c.use_mix = use_mix; c.rw1 = rw1;
+    c.seg_possible = seg_possible; c.one_ok = one_ok && (xmask & 0xafu) == 0; c.use_mix = use_mix; c.rw1 = rw1; c.seg_mix = seg_mix;
     return c;
 }
 
@@ -329,7 +347,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     AlignArgs a = *args;
     const DevParams &p = a.p;
     const int nk = (a.C + 15) / 16;
-    const CallPlan cp = plan_call(a.B, a.C, a.Smax, p, a.frame_ph && a.frame_idx);
+    const CallPlan cp = plan_call(a.B, a.C, a.Smax, p, a.frame_ph && a.frame_idx, a.wide_any_max);
     const int Lmax = 4 * a.Smax + 1;
     unsigned mask = cp.mask;
     const unsigned wmask = cp.wmask, xmask = cp.xmask;
@@ -359,6 +377,8 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
     if (seg_possible) bfa_launch_segment_plan(&a, stream);
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+    a.mix_exact_only = cp.seg_mix ? 1 : 0;
+    if (cp.seg_mix) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
     if (use_mix) {
         hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
         // the narrow classes are k_mix's: the class kernels below only see what it does not take
@@ -368,7 +388,7 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // (silence-anchored mode on the two head widths: the narrow classes are one launch on the caller's stream, bfa_dp3.inc)
     const bool merged_narrow = mode == 1 && (a.C == 67 || a.C == 17);
     const unsigned kmask = merged_narrow ? (mask & ~3u) : mask;
-    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + __builtin_popcount(xmask & 0xafu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0) + (use_mix ? 1 : 0);
+    const int n_kernels = __builtin_popcount(kmask & 0xf7fu) + __builtin_popcount(xmask & 0xafu) + ((merged_narrow && (mask & 3u)) ? 1 : 0) + (Lmax > 1024 ? 1 : 0) + ((use_mix || cp.seg_mix) ? 1 : 0);
     LaunchFan fan;
     fan.main_stream = stream;
     fan.aux = (hipStream_t *)aux_streams + aux_first;   // (the caller's share of the handle's streams: bfa_align_heads gives each head its own)
@@ -391,6 +411,10 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
             else bfa_launch_dp_big_nk8(&a, big_grid, bs, huge);
         }
         if (per_class_k2) bfa_launch_backtrace_sel(&a, K2_BIG, fused_k2 ? 1 : 0, dp_grid, bs, 2);
+    }
+    if (cp.seg_mix) { // the fallbacks of a silence-anchored call: on the shared third auxiliary stream, beside the pieces (caller's stream)
+        hipStream_t ms = fan.lane(2);
+        if (a.C == 67) bfa_k1_mix_nk5(&a, a.mix_order, ms); else bfa_k1_mix_nk2(&a, a.mix_order, ms);
     }
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);

@@ -170,13 +170,17 @@ __device__ __noinline__ float2 row_stats_on_demand(const float *row, int C, floa
         for (int c = 1; c < C; ++c) total = total + expf_u10(row[c] - mx);
         ls = logf_u10(total);
     } else {
-        float acc[16];
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-        for (int c = 0; c < C; ++c) {
-            const float e = expf_u10(row[c] - mx);
-            acc[c & 15] = (c < 16) ? e : (acc[c & 15] + e);
+        float acc[16]; // (indexed by unrolled constants only: `acc[c & 15]` put the array -- and 2 x C scratch accesses per call -- into private memory)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = expf_u10(row[j] - mx);
+        for (int c0 = 16; c0 < C; c0 += 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (c0 + j < C) acc[j] = acc[j] + expf_u10(row[c0 + j] - mx);
         }
+#pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = acc[j] + acc[j + 8];   // xor 8
+#pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = acc[j] + acc[j + 4];   // xor 4
         ls = logf_u10((acc[0] + acc[2]) + (acc[1] + acc[3]));        // xor 2, xor 1
     }

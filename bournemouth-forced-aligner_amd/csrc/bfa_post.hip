@@ -225,7 +225,11 @@ struct PostConfArgs {
 #ifndef BFA_POST_NW4_MAX_BATCH
 #define BFA_POST_NW4_MAX_BATCH 512
 #endif
-constexpr int STAGE_K = BFA_STAGE_K; // frames staged on either side of a tuple (probes beyond fall back to memory)
+constexpr int STAGE_K = BFA_STAGE_K;
+#ifndef BFA_POST_WIDE_REACH
+#define BFA_POST_WIDE_REACH 96
+#endif
+constexpr int POST_WIDE_REACH = BFA_POST_WIDE_REACH; // frames a wide window reaches beyond its tuple (k_postconf, rounds 1 / 2) // frames staged on either side of a tuple (probes beyond fall back to memory)
 
 template <bool RAW>
 struct StagedProb {
@@ -402,11 +406,15 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
         for (int round = 0; round < 3; ++round) {
             if (staging && (round == 0 || wide)) {
                 if (round) post_sync();
-                int W = 1 << 20, tot = 0;
+                // (POST_WIDE_REACH frames beyond the +-K margin at most: the walks of more than 32 frames are the whole wave's, 64
+                // probes per step, and go on through memory at the same price; staging a window's full reach made every padded row
+                // up to Tmax a cell of the last tuple -- rows whose statistics nobody has, eleven one-lane-per-row softmax calls per
+                // wave on the C5 proxy at peak 3, profiles/r06_postconf_pmc_c5p3.txt)
+                int W = POST_WIDE_REACH, tot = 0;
                 for (;;) { // the widest reach whose cells fit the LDS (a probe beyond it reads memory)
                     tot = assign_windows(round, W);
                     if (tot <= a.cap_cells || W <= 1 || round == 0) break;
-                    W = (W > 256) ? 256 : (W >> 1);
+                    W >>= 1;
                     post_sync();
                 }
                 if (tot > a.cap_cells) { // more cells than the LDS holds (overlapping caller-made tuples): nothing is staged
@@ -476,41 +484,77 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                 // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
                 const int p_last = round == 1 ? 3 : 4;
                 for (int pass = round == 1 ? 1 : 4; pass <= p_last; ++pass) {
-                    for (int i = tid; i < m; i += NT) {
-                        const int ph = st[i].phoneme, s = st[i].start, e = st[i].end;
-                        if (s >= Tpad || ph >= a.C) continue; // :719,:740,:760,:784
+                    // A walk is a scan for the first frame below the threshold, left of the start or right of the end, up to a
+                    // limit.  Tuple per lane it is one dependent LDS probe per frame: fine for the usual few frames, but on soft
+                    // posteriors -- or behind an utterance that ended at the sentinel, whose tuples can lie a thousand frames
+                    // apart -- single lanes walked ~10^3 frames while their wave waited (C5 proxy at peak 3: k_postconf 1.7 + 3.1
+                    // of a 7.9-ms call, profiles/r06_c5proxy_p3_timeline_mid.txt).  Walks of more than 32 frames are taken by the
+                    // whole wave, 64 frames per step: one probe per lane, one ballot, the first failing lane ends the walk.
+                    for (int base = wave * 64; base < m; base += NT) {
+                        const int i = base + lane;
+                        bool act = i < m;
+                        int ph = 0, s = 0, e = 0;
+                        if (act) { ph = st[i].phoneme; s = st[i].start; e = st[i].end; if (s >= Tpad || ph >= a.C) act = false; } // :719,:740,:760,:784
                         const int d = e - s;
-                        if (pass == 1) { // :717-735
-                            int min_start = (int)((double)s - (double)d * 10.0);
-                            if (min_start < 0) min_start = 0;
-                            if (i > 0) { int v = st[i - 1].end + 10; if (v > s) v = s; if (v > min_start) min_start = v; }
-                            double thr = smean[i] * th1; if (thr > th1) thr = th1;
-                            int ns = s;
-                            for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= thr) ns = f; else break; }
-                            st[i].start = ns;
-                        } else if (pass == 2) { // :738-755
-                            int max_end = (int)((double)e + (double)d * 10.0);
-                            if (max_end > Tpad) max_end = Tpad;
-                            if (i + 1 < m) { int v = st[i + 1].start - 10; if (v > e) v = e; if (v < max_end) max_end = v; }
-                            double thr = smean[i] * th1; if (thr > th1) thr = th1;
-                            int ne = e;
-                            for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= thr) ne = f + 1; else break; }
-                            st[i].end = ne;
-                        } else if (pass == 3) { // :758-778
-                            int min_start = 0;
-                            if (i > 0) min_start = st[i - 1].end;
-                            if (s <= min_start) continue;
-                            int ns = s;
-                            for (int f = s - 1; f >= min_start; --f) { if ((double)pr.at(i, f, ph) >= th2) ns = f; else break; }
-                            st[i].start = ns;
-                        } else { // :782-805
-                            int max_end = (int)((double)e + (double)d * 10.0);
-                            if (max_end > Tpad) max_end = Tpad;
-                            if (i + 1 < m) { const int v = st[i + 1].start; if (v < max_end) max_end = v; }
-                            int ne = e;
-                            for (int f = e; f < max_end; ++f) { if ((double)pr.at(i, f, ph) >= th2) ne = f + 1; else break; }
-                            st[i].end = ne;
+                        int dir = (pass == 1 || pass == 3) ? -1 : 1; // -1: probes s - 1 down to `lim` (inclusive); +1: e up to `lim` (exclusive)
+                        int lim = 0;
+                        double thr = th2;
+                        if (act) {
+                            if (pass == 1) { // :717-735
+                                int min_start = (int)((double)s - (double)d * 10.0);
+                                if (min_start < 0) min_start = 0;
+                                if (i > 0) { int v = st[i - 1].end + 10; if (v > s) v = s; if (v > min_start) min_start = v; }
+                                thr = smean[i] * th1; if (thr > th1) thr = th1;
+                                lim = min_start;
+                            } else if (pass == 2) { // :738-755
+                                int max_end = (int)((double)e + (double)d * 10.0);
+                                if (max_end > Tpad) max_end = Tpad;
+                                if (i + 1 < m) { int v = st[i + 1].start - 10; if (v > e) v = e; if (v < max_end) max_end = v; }
+                                thr = smean[i] * th1; if (thr > th1) thr = th1;
+                                lim = max_end;
+                            } else if (pass == 3) { // :758-778
+                                int min_start = 0;
+                                if (i > 0) min_start = st[i - 1].end;
+                                if (s <= min_start) act = false;
+                                lim = min_start;
+                            } else { // :782-805
+                                int max_end = (int)((double)e + (double)d * 10.0);
+                                if (max_end > Tpad) max_end = Tpad;
+                                if (i + 1 < m) { const int v = st[i + 1].start; if (v < max_end) max_end = v; }
+                                lim = max_end;
+                            }
                         }
+                        const int f0 = dir < 0 ? s - 1 : e;                       // first frame probed
+                        const int len = act ? (dir < 0 ? f0 - lim + 1 : lim - f0) : 0; // frames the walk may probe
+                        int res = dir < 0 ? s : e;
+                        const bool lng = len > 32;
+                        if (act && !lng) {
+                            if (dir < 0) { for (int f = f0; f >= lim; --f) { if ((double)pr.at(i, f, ph) >= thr) res = f; else break; } }
+                            else { for (int f = f0; f < lim; ++f) { if ((double)pr.at(i, f, ph) >= thr) res = f + 1; else break; } }
+                        }
+                        unsigned long long pend = __ballot(act && lng);
+                        while (pend) {
+                            const int src = __builtin_ctzll(pend);
+                            pend &= pend - 1ull;
+                            const int ci = __shfl(i, src), cph = __shfl(ph, src), cf0 = __shfl(f0, src), cn = __shfl(len, src), clim = __shfl(lim, src);
+                            const long long tb = __builtin_bit_cast(long long, thr);
+                            const unsigned tlo = (unsigned)__shfl((int)(tb & 0xffffffffll), src), thi = (unsigned)__shfl((int)(tb >> 32), src);
+                            const double cthr = __builtin_bit_cast(double, (long long)(((unsigned long long)thi << 32) | tlo));
+                            int r = clim; // nothing fails: the walk ends at its limit (left: start = lim, right: end = lim)
+                            for (int c0 = 0; c0 < cn; c0 += 64) {
+                                const int k = c0 + lane;
+                                bool fail = false;
+                                if (k < cn) fail = !((double)pr.at(ci, dir < 0 ? cf0 - k : cf0 + k, cph) >= cthr);
+                                const unsigned long long fm = __ballot(fail);
+                                if (fm) {
+                                    const int kf = c0 + __builtin_ctzll(fm);
+                                    r = dir < 0 ? cf0 - kf + 1 : cf0 + kf; // left: the frame behind the first failing one; right: the failing frame
+                                    break;
+                                }
+                            }
+                            if (lane == src) res = r;
+                        }
+                        if (act) { if (dir < 0) st[i].start = res; else st[i].end = res; }
                     }
                     post_sync();
                 }

@@ -163,6 +163,7 @@ struct AlignArgs {
     int32_t *hist;
     int32_t hist_tag;
     int32_t wide_any_max;   // silence-anchored mode: calls of at most this many utterances take the wide classes as ONE launch, slots included (k_dp5_any)
+    int32_t mix_exact_only; // k_mix in a silence-anchored call: the exact-window utterance slots (standard-mode fallbacks) only
     int32_t pieces_merged;  // launcher: the pieces of the wide classes are k_dp5_any's, the class kernels take the utterance slots only
 };
 constexpr int K2_ALL = 0, K2_REST = 1, K2_BIG = 2, K2_WIN = 3, K2_REST_NOWIN = 4, K2_XWIN = 5, K2_FULL = 16; // K2_FULL + R, R in {2,3,4,6,8,12,16}
