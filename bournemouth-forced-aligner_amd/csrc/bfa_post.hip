@@ -227,7 +227,7 @@ struct PostConfArgs {
 #endif
 constexpr int STAGE_K = BFA_STAGE_K;
 #ifndef BFA_POST_WIDE_REACH
-#define BFA_POST_WIDE_REACH 96
+#define BFA_POST_WIDE_REACH 192
 #endif
 constexpr int POST_WIDE_REACH = BFA_POST_WIDE_REACH; // frames a wide window reaches beyond its tuple (k_postconf, rounds 1 / 2) // frames staged on either side of a tuple (probes beyond fall back to memory)
 
