@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                     // limit.  Tuple per lane it is one dependent LDS probe per frame: fine for the usual few frames, but on soft
                     // posteriors -- or behind an utterance that ended at the sentinel, whose tuples can lie a thousand frames
                     // apart -- single lanes walked ~10^3 frames while their wave waited (C5 proxy at peak 3: k_postconf 1.7 + 3.1
-                    // of a 7.9-ms call, profiles/r06_c5proxy_p3_timeline_mid.txt).  Walks of more than 32 frames are taken by the
+                    // of a 7.9-ms call; the first sweep, profiles/r06_c5proxy_p3_timeline_before.txt, has 12.5 ms per head).  Walks of more than 32 frames are taken by the
                     // whole wave, 64 frames per step: one probe per lane, one ballot, the first failing lane ends the walk.
                     for (int base = wave * 64; base < m; base += NT) {
                         const int i = base + lane;
