@@ -257,6 +257,13 @@ struct CallPlan {
     int rw1;
 };
 
+// (A/B: BFA_NO_WIDE_XWIN=1 keeps the full layout for the wide fallbacks of silence-anchored calls, as before round 6)
+static bool seg_wide_xwin()
+{
+    static const bool on = [] { const char *e = std::getenv("BFA_NO_WIDE_XWIN"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frames, int wide_any_max = 256)
 {
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
@@ -322,6 +329,20 @@ static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frame
         seg_mix = w4 != 0u;
         if (!seg_mix) xmask = 0;
     }
+    // ... and the fallbacks of the WIDE window classes Rw = 6 / 8 -- the longest utterances of a call: 30-s segments with 100-150
+    // targets, whose full layout is the class R = 8 / 12 / 16 -- as exact-window items of their class kernels (k_dp4x<6 / 8>: the
+    // in-band states only, half of the full layout's, and the closed-form dead tails): C5 proxy 4.65 -> 4.43 ms at peak 9, 5.10 ->
+    // 4.40 at peak 3 (profiles/r06_wide_xwin_ab.txt).  Full batches only: in a small call the two class kernels are two more
+    // streams, and the runtime put each on the OTHER head's hardware queue -- the reference's sixteen-utterance chunk 0.97 -> 1.69 ms
+    // although the chain itself got shorter (k_dp4x<6> 341 + 50 us against k_dp5_any's 470; same file).  Only where the full-layout
+    // classes such an utterance would take can occur at all (Rw 6: R >= 8, Rw 8: R >= 12; `mask` holds the hint).
+    if (mode == 1 && (C == 67 || C == 17) && Lmax > 60 && p.min_logp <= 0.0f && frames && B > wide_any_max && seg_wide_xwin()) {
+        unsigned w68 = 0;
+        const int top = win_class_for(Lmax, (Lmax / 4 > 20) ? Lmax / 4 : 20, 1);
+        if (top >= 6 && (mask & (16u | 32u | 64u))) w68 |= 0x20u;
+        if (top >= 8 && (mask & (32u | 64u))) w68 |= 0x80u;
+        xmask |= w68;
+    }
     mask |= (xmask & 0xafu) << 20;
     CallPlan c;
     c.mode = mode; c.mask = mask; c.wmask = wmask; c.wall = wall; c.xmask = xmask; c.hinted = hinted;
@@ -340,8 +361,10 @@ extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
                                 void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx,
-                                int aux_first, int aux_count)
+                                int aux_first, int aux_count, int phase)
 {
+    // phase 0: the whole call; 1: its front only (k_plan and the silence-anchored mode's K0 + planner); 2: the rest (bfa_capi.cpp:
+    // bfa_align_heads enqueues the fronts of all heads first)
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
     AlignArgs a = *args;
@@ -368,19 +391,22 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
     if (cp.one_ok) {
+        if (phase == 1) return 0;
         a.p.xwin_mask = 0; // (k_one reruns its own window failures with the full layout)
         if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
         if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);
         if (ev1) (void)hipEventRecord((hipEvent_t)ev1, stream);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
-    if (seg_possible) bfa_launch_segment_plan(&a, stream);
-    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
     a.mix_exact_only = cp.seg_mix ? 1 : 0;
-    if (cp.seg_mix) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
+    if (phase != 2) {
+        hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+        if (seg_possible) bfa_launch_segment_plan(&a, stream);
+        if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+        if (cp.seg_mix || use_mix) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
+        if (phase == 1) return (int)hipGetLastError();
+    }
     if (use_mix) {
-        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
         // the narrow classes are k_mix's: the class kernels below only see what it does not take
         mask &= ~(7u | (0xfu << 20));
     }

@@ -20,6 +20,14 @@ __device__ __forceinline__ void post_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// -DBFA_POST_TIMES (A/B builds, tools/post_stamps.py): cycles per phase of k_postconf, summed over the utterances of a launch
+#ifdef BFA_POST_TIMES
+__device__ unsigned long long g_post_times[16];
+#define POST_STAMP(k) do { const long long t1_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_post_times[k], (unsigned long long)(t1_ - t0_)); t0_ = clock64(); } while (0)
+#else
+#define POST_STAMP(k) do { } while (0)
+#endif
+
 struct PostArgs {
     const float *logp;
     float *row_stats; // != nullptr: logp is raw logits (AlignArgs::row_stats)
@@ -251,7 +259,7 @@ struct StagedProb {
 // staging (cells, exponentials), the means, the passes and the confidences are shared out over 256 lanes, the prefix sums of the
 // window layout stay with wave 0, and the wave-level syncs become workgroup barriers.  Full batches keep NW = 1.
 template <bool RAW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void k_postconf(PostConfArgs a)
 {
     __shared__ int s_flag, s_tot, s_m;
     constexpr int NT = 64 * NW;
@@ -281,6 +289,9 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
         bfa_segment *sg = a.segs + (int64_t)b * a.seg_cap;
         const LpView<RAW> lp{a.logp + (int64_t)b * a.strideB, a.strideT,
                              RAW ? a.row_stats + 2 * (int64_t)b * a.Tmax : nullptr, a.C};
+#ifdef BFA_POST_TIMES
+        long long t0_ = clock64();
+#endif
         int n = a.seg_count[b];
         if (n > a.seg_cap) n = a.seg_cap;
         int m = n;
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
             for (int i = tid; i < m; i += NT) st[i] = sg[i];
             post_sync();
         }
+        POST_STAMP(0);
         const int Tpad = a.Tmax;                      // the soft-boundary stage works on the padded rows (core.py:705)
         int Tc = a.T_rows ? a.T_rows[b] : a.Tmax;     // the confidence pass on log_probs.shape[0] as the caller passes it
         if (Tc > a.Tmax) Tc = a.Tmax;
@@ -371,27 +383,60 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
         // ---- stage: cell c belongs to the tuple i with off[i] <= c < off[i] + len_i (binary search), frame wlo[i] + (c - off[i])
         auto stage_cells = [&](int total) {
             constexpr int U = 8;
+            // steps of the search below: the same for every lane and cell, so that the U searches of a lane run side by side
+            // (one LDS round trip per step for all of them; with a trip count of its own per cell they ran one behind the other)
+            int nstep = 0;
+            while ((1 << nstep) < m) ++nstep;
             for (int c0 = wave * 64 * U; c0 < total; c0 += NT * U) {
                 float x[U];
                 float2 ms[U];
-                int cell[U];
+                {
+                    int own[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = min(c0 + u * 64 + lane, total - 1);
-                    int lo_i = 0, hi_i = m - 1; // last tuple with off <= c (empty windows share their successor's offset)
-                    while (lo_i < hi_i) { const int mid = (lo_i + hi_i + 1) >> 1; if (off[mid] <= c) lo_i = mid; else hi_i = mid - 1; }
-                    const int f = wlo[lo_i] + (c - off[lo_i]);
-                    const int ph = st[lo_i].phoneme;
-                    cell[u] = c;
-                    x[u] = lp.lp[(int64_t)f * lp.ld + ph];
-                    if (RAW) ms[u] = *(const float2 *)(lp.st + 2 * (int64_t)f);
-                    else ms[u] = make_float2((float)f, (float)ph); // (unused)
-                    if (RAW && (ms[u].x != ms[u].x || ms[u].y != ms[u].y)) ms[u] = row_stats_on_demand(lp.lp + (int64_t)f * lp.ld, lp.C, lp.st + 2 * (int64_t)f);
+                    for (int u = 0; u < U; ++u) own[u] = 0;
+                    // last tuple with off <= c (empty windows share their successor's offset): binary lifting over [0, m)
+                    for (int st_ = nstep - 1; st_ >= 0; --st_) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int cand = own[u] + (1 << st_);
+                            if (cand < m && off[cand] <= min(c0 + u * 64 + lane, total - 1)) own[u] = cand;
+                        }
+                    }
+                    // ALL loads of the round first -- 2 U of them in flight -- and only then the test for rows without statistics:
+                    // with the test (and its call, which stores the row's statistics) behind each pair of loads the next pair
+                    // could not be moved above it, and a round of U cells was U memory round trips one behind the other: 65 % of
+                    // the wave's cycles on the real-text batch (tools/post_stamps.py, profiles/r06_postconf_stamps.txt)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int f = wlo[own[u]] + (min(c0 + u * 64 + lane, total - 1) - off[own[u]]);
+                        x[u] = lp.lp[(int64_t)f * lp.ld + st[own[u]].phoneme];
+                        if (RAW) ms[u] = *(const float2 *)(lp.st + 2 * (int64_t)f);
+                        else ms[u] = make_float2(0.0f, 0.0f); // (unused)
+                    }
+                }
+                if (RAW) {
+                    bool need = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) need = need || (ms[u].x != ms[u].x || ms[u].y != ms[u].y);
+                    if (__any(need)) {
+                        // padded rows beyond the ones K0 left statistics for (rare): the round cell by cell, nothing kept in
+                        // registers across the one-lane-per-row softmax calls
+#pragma unroll 1
+                        for (int u = 0; u < U; ++u) {
+                            const int c = c0 + u * 64 + lane;
+                            if (c >= total) break;
+                            int o = 0;
+                            for (int st_ = nstep - 1; st_ >= 0; --st_) { const int cand = o + (1 << st_); if (cand < m && off[cand] <= c) o = cand; }
+                            const int f = wlo[o] + (c - off[o]);
+                            sp[c] = exp_cr(lp.at(f, st[o].phoneme));
+                        }
+                        continue;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float v = RAW ? ((x[u] - ms[u].x) - ms[u].y) : x[u];
-                    if (c0 + u * 64 + lane < total) sp[cell[u]] = exp_cr(v);
+                    if (c0 + u * 64 + lane < total) sp[min(c0 + u * 64 + lane, total - 1)] = exp_cr(v);
                 }
             }
         };
@@ -424,8 +469,10 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                 }
                 total = tot;
                 post_sync();
+                POST_STAMP(1);
                 stage_cells(total);
                 post_sync();
+                POST_STAMP(2);
             }
             if (!ext) break;
             if (round == 0) {
@@ -442,6 +489,7 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                     smean[i] = mean;
                 }
                 post_sync();
+                POST_STAMP(3);
                 // ---- Can a walk of the passes below leave its tuple's staged window?  Only if every staged margin cell on that side
                 // is at or above the smallest threshold any pass compares it with (the walks stop at the first cell below theirs) and
                 // the window does not already reach the neighbour.  On sharp posteriors no tuple qualifies and this costs 2 K LDS
@@ -480,6 +528,7 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                     }
                     wide = any_wg(anyw) ? 1 : 0;
                 }
+                POST_STAMP(4);
             } else {
                 // ---- the four passes (core.py:717-805); a pass only reads neighbour fields it does not write
                 const int p_last = round == 1 ? 3 : 4;
@@ -558,6 +607,7 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
                     }
                     post_sync();
                 }
+                POST_STAMP(5);
             }
         }
         if (a.do_post) {
@@ -570,16 +620,30 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
             for (int i = (m < 0 ? 0 : m) + tid; i < a.seg_cap; i += NT) cf[i] = 0.0f; // the caller's buffer needs no fill ahead of the call
             int bad = 0;
             // does any tuple read a cell that an earlier tuple has written through its 0-dim view?
-            int alias = 0;
-            for (int i = tid; i < m; i += NT) {
-                const int ph = st[i].phoneme;
-                const int s = max(0, st[i].start), e = min(Tc, st[i].end);
-                for (int k = 0; k < i; ++k) {
-                    if (st[k].phoneme != ph) continue;
-                    const int sk = max(0, st[k].start);
-                    if (sk == s || (sk >= s && sk < e)) { alias = 1; break; }
+            // (with the starts in non-decreasing order -- what an alignment's tuples are -- an earlier tuple can only share a later
+            // one's cells if it STARTS on the same frame: the tuples right before i with that start are all there is to look at;
+            // the all-pairs test, 11 % of the wave's cycles on 150-tuple utterances, is left for tuples in another order)
+            int alias = 0, unord = 0;
+            for (int i = tid; i + 1 < m; i += NT) if (max(0, st[i].start) > max(0, st[i + 1].start)) unord = 1;
+            if (!any_wg(unord)) {
+                for (int i = tid; i < m; i += NT) {
+                    const int ph = st[i].phoneme;
+                    const int s = max(0, st[i].start);
+                    for (int k = i - 1; k >= 0 && max(0, st[k].start) == s; --k)
+                        if (st[k].phoneme == ph) { alias = 1; break; }
+                }
+            } else {
+                for (int i = tid; i < m; i += NT) {
+                    const int ph = st[i].phoneme;
+                    const int s = max(0, st[i].start), e = min(Tc, st[i].end);
+                    for (int k = 0; k < i; ++k) {
+                        if (st[k].phoneme != ph) continue;
+                        const int sk = max(0, st[k].start);
+                        if (sk == s || (sk >= s && sk < e)) { alias = 1; break; }
+                    }
                 }
             }
+            POST_STAMP(6);
             alias = any_wg(alias) ? 1 : 0;
             if (!alias) {
                 for (int i = tid; i < m; i += NT) {
@@ -644,6 +708,7 @@ __global__ __launch_bounds__(64 * NW) void k_postconf(PostConfArgs a)
             } else {
                 bad = 1;
             }
+            POST_STAMP(7);
             bad = any_wg(bad) ? 1 : 0;
             if (tid == 0 && a.status) a.status[b] = bad ? BFA_ITEM_BAD_TOKEN : BFA_ITEM_OK;
         }
@@ -687,6 +752,15 @@ extern "C" int bfa_launch_postprocess(const float *logp, float *row_stats, int64
     else hipLaunchKernelGGL((k_postprocess<false, false>), dim3(grid), dim3(64), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
+
+#ifdef BFA_POST_TIMES
+extern "C" __attribute__((visibility("default"))) int bfa_dbg_post_times(unsigned long long *out, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bfa::g_post_times), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(bfa::g_post_times), z, sizeof(z)); }
+    return rc;
+}
+#endif
 
 // postprocess and / or confidences of a batch through k_postconf; returns -1 when the shapes do not fit its LDS staging
 extern "C" int bfa_launch_postconf(const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
