@@ -16,7 +16,7 @@
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream, void *ev0, void *ev1,
                                 void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx,
-                                int aux_first, int aux_count, int phase);
+                                int aux_first, int aux_count);
 extern "C" int bfa_launch_conf(const bfa::ConfArgs *args, void *stream);
 extern "C" int bfa_launch_prepare(const bfa::AlignArgs *args, float *out, int64_t oB, int64_t oT, void *stream);
 extern "C" int bfa_launch_log_softmax(const float *in, int64_t ld_in, float *out, int64_t ld_out, int64_t rows,
@@ -394,36 +394,11 @@ int bfa_call_counters(bfa_handle h, const void *workspace, int B, int Tmax, int 
 
 } // extern "C"
 
-// A call as align_prepare leaves it: the kernel arguments and what the launches need.  align_launch(.., phase) then enqueues
-// the FRONT of the call (k_plan, K0, the segment planner), its BACK (the DP kernels, the walks, the tuples) or both
-// (phase 1 / 2 / 0): bfa_align_heads enqueues the fronts of all heads before any head's class kernels.  The auxiliary streams
-// of one head share hardware queues with the other head's stream, and enqueued head by head the second head's first kernel
-// sat 0.87 ms behind the first head's wide class kernel in a call of mixed lengths (profiles/r06_c5proxy_timeline.txt).
-struct PreparedCall {
-    bfa::AlignArgs a;
-    int grid, aux_set;
-    void *ev0, *ev1, *stream;
-};
-
-static int align_launch(bfa_handle h, const PreparedCall &pc, int phase)
-{
-    // the heads of one bfa_align_heads call fan out over DIFFERENT halves of the handle's auxiliary streams (aux_set 0 / 1:
-    // three streams each -- the class kernels are laid out on three, bfa_dp3.inc launch3): on the same ones the class kernels
-    // of the second head queued behind the first head's (profiles/r06_latency_realtext_timeline_b16_before.txt)
-    const int half = bfa_context::NAUX / 2;
-    const int aux_set = pc.aux_set;
-    const int rc = bfa_launch_align(&pc.a, pc.grid, pc.stream, pc.ev0, pc.ev1, (void **)h->aux, (void **)h->aux_done,
-                                    (void **)((aux_set > 0 && (aux_set & 1)) ? &h->forked_b : &h->forked), ensure_aux, (void *)h,
-                                    aux_set < 0 ? 0 : half * (aux_set & 1), aux_set < 0 ? bfa_context::NAUX : half, phase);
-    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
-    return BFA_OK;
-}
-
-static int align_prepare(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
-                         const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
-                         const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
-                         bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
-                         int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream, int aux_set, PreparedCall *pc)
+static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
+                    const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
+                    const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
+                    bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
+                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream, int aux_set = -1)
 {
     if (!h) return BFA_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(h);
@@ -515,23 +490,15 @@ static int align_prepare(bfa_handle h, const float *logp, float *row_stats, int6
     }
     a.wide_any_max = h->wide_any_max;
     a.pieces_merged = h->wide_any_max >= 0 ? 1 : 0;
-    pc->a = a; pc->grid = grid; pc->aux_set = aux_set; pc->ev0 = ev0; pc->ev1 = ev1; pc->stream = stream;
+    // the heads of one bfa_align_heads call fan out over DIFFERENT halves of the handle's auxiliary streams (aux_set 0 / 1:
+    // three streams each -- the class kernels are laid out on three, bfa_dp3.inc launch3): on the same ones the class kernels
+    // of the second head queued behind the first head's (profiles/r06_latency_realtext_timeline_b16_before.txt)
+    const int half = bfa_context::NAUX / 2;
+    const int rc = bfa_launch_align(&a, grid, stream, ev0, ev1, (void **)h->aux, (void **)h->aux_done,
+                                    (void **)((aux_set > 0 && (aux_set & 1)) ? &h->forked_b : &h->forked), ensure_aux, (void *)h, aux_set < 0 ? 0 : half * (aux_set & 1), aux_set < 0 ? bfa_context::NAUX : half);
+    if (rc != 0) return fail(h, BFA_ERR_LAUNCH, hipGetErrorString((hipError_t)rc));
     return BFA_OK;
 }
-
-static int align_impl(bfa_handle h, const float *logp, float *row_stats, int64_t strideB, int64_t strideT, int B, int Tmax, int C,
-                    const int32_t *T_len, const int32_t *tokens, const int32_t *S_len, int Smax,
-                    const bfa_params *params, int32_t *out_frame_phoneme, int32_t *out_frame_idx,
-                    bfa_segment *out_segs, int seg_cap, int32_t *out_seg_count, int32_t *out_status,
-                    int32_t *out_mode, void *workspace, size_t workspace_bytes, void *stream, int aux_set = -1)
-{
-    PreparedCall pc;
-    const int rc = align_prepare(h, logp, row_stats, strideB, strideT, B, Tmax, C, T_len, tokens, S_len, Smax, params, out_frame_phoneme,
-                                 out_frame_idx, out_segs, seg_cap, out_seg_count, out_status, out_mode, workspace, workspace_bytes, stream,
-                                 aux_set, &pc);
-    return rc != BFA_OK ? rc : align_launch(h, pc, 0);
-}
-
 
 extern "C" {
 
@@ -576,19 +543,16 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
     }
     int rc = BFA_OK;
     // the later heads first; head 0 (the wide phoneme head) last: its kernels are the long ones, the others fill in beside them
-    PreparedCall pcs[8];
-    for (int k = n_heads - 1; k >= 0 && rc == BFA_OK; --k) { // every head's front (plan, K0, segment planner) before any head's class kernels
-        const bfa_head &hd = heads[k];
-        void *st = paired ? (void *)h->pair[k & 1] : ((side && k > 0) ? (void *)h->head_stream : stream);
-        rc = align_prepare(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, T_len, hd.tokens, S_len,
-                           hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
-                           hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st, n_heads > 1 ? k : -1, &pcs[k]);
-        if (rc == BFA_OK) rc = align_launch(h, pcs[k], n_heads > 1 ? 1 : 0);
-    }
+    // (Head by head.  Enqueueing the fronts of all heads -- plan, K0, segment planner -- before any head's class kernels was built
+    // and measured: the second head then starts at once instead of behind the first head's class kernel on a shared hardware
+    // queue, but the staggered start is the better schedule -- one head's memory-bound K0 beside the other's latency-bound chains:
+    // C5 proxy 4.12 against 4.47 ms at peak 9, 3.96 against 4.42 at peak 3, profiles/r06_heads_fronts_first_ab.txt.)
     for (int k = n_heads - 1; k >= 0 && rc == BFA_OK; --k) {
         const bfa_head &hd = heads[k];
         void *st = paired ? (void *)h->pair[k & 1] : ((side && k > 0) ? (void *)h->head_stream : stream);
-        if (n_heads > 1) rc = align_launch(h, pcs[k], 2);
+        rc = align_impl(h, hd.logits, hd.out_row_stats, hd.strideB, hd.strideT, B, Tmax, hd.C, T_len, hd.tokens, S_len,
+                        hd.Smax, &hd.params, hd.out_frame_phoneme, hd.out_frame_idx, hd.out_segs, hd.seg_cap,
+                        hd.out_seg_count, hd.out_status, hd.out_mode, hd.workspace, hd.workspace_bytes, st, n_heads > 1 ? k : -1);
         // core.py:925-937 for this head on ITS stream: coverage + soft boundaries, then the confidences of the final tuples
         // -- in ONE kernel when both are asked for and the shapes fit its LDS staging (bfa_post.hip: k_postconf)
         if (rc == BFA_OK && hd.postprocess && hd.out_conf && staged_post() && hd.seg_cap <= 6500) {

@@ -361,10 +361,8 @@ extern "C" int bfa_call_path_impl(int B, int C, int Smax, const bfa::DevParams *
 
 extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *stream_, void *ev0, void *ev1,
                                 void **aux_streams, void **aux_events, void **fork_event, int (*ensure_aux)(void *), void *ctx,
-                                int aux_first, int aux_count, int phase)
+                                int aux_first, int aux_count)
 {
-    // phase 0: the whole call; 1: its front only (k_plan and the silence-anchored mode's K0 + planner); 2: the rest (bfa_capi.cpp:
-    // bfa_align_heads enqueues the fronts of all heads first)
     using namespace bfa;
     hipStream_t stream = (hipStream_t)stream_;
     AlignArgs a = *args;
@@ -391,7 +389,6 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
     // Small batches of ONE sliding-window class (by the caller's hint): plan + window DP + rerun + walk in one kernel, one
     // workgroup per utterance (bfa_dp4.inc: k_one).  The serial chain of the DP is all that is left of the call.
     if (cp.one_ok) {
-        if (phase == 1) return 0;
         a.p.xwin_mask = 0; // (k_one reruns its own window failures with the full layout)
         if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
         if (a.C == 67) bfa_k1_one_nk5(&a, rw1, stream); else bfa_k1_one_nk2(&a, rw1, stream);
@@ -399,13 +396,10 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         return (int)hipGetLastError();
     }
     a.mix_exact_only = cp.seg_mix ? 1 : 0;
-    if (phase != 2) {
-        hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
-        if (seg_possible) bfa_launch_segment_plan(&a, stream);
-        if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
-        if (cp.seg_mix || use_mix) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
-        if (phase == 1) return (int)hipGetLastError();
-    }
+    hipLaunchKernelGGL(k_plan, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    if (seg_possible) bfa_launch_segment_plan(&a, stream);
+    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, stream);
+    if (cp.seg_mix || use_mix) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, a);
     if (use_mix) {
         // the narrow classes are k_mix's: the class kernels below only see what it does not take
         mask &= ~(7u | (0xfu << 20));
