@@ -432,13 +432,16 @@ extern "C" int bfa_launch_align(const bfa::AlignArgs *args, int dp_grid, void *s
         }
         if (per_class_k2) bfa_launch_backtrace_sel(&a, K2_BIG, fused_k2 ? 1 : 0, dp_grid, bs, 2);
     }
-    if (cp.seg_mix) { // the fallbacks of a silence-anchored call: on the shared third auxiliary stream, beside the pieces (caller's stream)
-        hipStream_t ms = fan.lane(2);
-        if (a.C == 67) bfa_k1_mix_nk5(&a, a.mix_order, ms); else bfa_k1_mix_nk2(&a, a.mix_order, ms);
-    }
+    // the fallbacks of a silence-anchored full batch: on the head's third auxiliary stream, beside the pieces (caller's stream) --
+    // forked here, ahead of the caller's-stream launches; k_mix itself goes behind the wide exact-window kernels of that lane
+    if (cp.seg_mix) (void)fan.lane(2);
     if (nk <= 2) bfa_launch_dp_nk2(&a, mask, mode, dp_grid, &fan);
     else if (nk <= 5) bfa_launch_dp_nk5(&a, mask, mode, dp_grid, &fan);
     else bfa_launch_dp_nk8(&a, mask, mode, dp_grid, &fan);
+    if (cp.seg_mix) {
+        hipStream_t ms = fan.lane(2);
+        if (a.C == 67) bfa_k1_mix_nk5(&a, a.mix_order, ms); else bfa_k1_mix_nk2(&a, a.mix_order, ms);
+    }
     if (use_mix) { // on the caller's stream, after the forks (the other classes' kernels run beside it)
         if (a.C == 67) bfa_k1_mix_nk5(&a, a.mix_order, stream); else bfa_k1_mix_nk2(&a, a.mix_order, stream);
     }

@@ -646,12 +646,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
             POST_STAMP(6);
             alias = any_wg(alias) ? 1 : 0;
             if (!alias) {
-                for (int i = tid; i < m; i += NT) {
-                    const int ph = st[i].phoneme;
-                    const int s = max(0, st[i].start), e = min(Tc, st[i].end); // :86-87
-                    if (s >= Tc || ph < 0 || ph >= a.C) { bad = 1; cf[i] = 0.0f; continue; } // IndexError at :89
-                    float c = pr.at(i, s, ph);
-                    if (s < e) {
+                // Tuple per lane; a tuple of more than CONF_COOP frames is taken by the whole wave -- 64 probes at a time, then the
+                // sum in frame order over the 64 values (the reference's float32 additions, :101-103, in its order).  On soft
+                // posteriors the extension passes leave tuples of hundreds of frames, longer than their staged windows: one memory
+                // probe per frame and lane, 41 % of the wave's cycles on the C5 proxy at peak 3 (profiles/r06_postconf_stamps.txt).
+                constexpr int CONF_COOP = 96;
+                for (int base = wave * 64; base < m; base += NT) {
+                    const int i = base + lane;
+                    bool ok = false;
+                    int ph = 0, s = 0, e = 0;
+                    float c = 0.0f;
+                    if (i < m) {
+                        ph = st[i].phoneme;
+                        s = max(0, st[i].start); e = min(Tc, st[i].end); // :86-87
+                        if (s >= Tc || ph < 0 || ph >= a.C) bad = 1; // IndexError at :89
+                        else { ok = true; c = pr.at(i, s, ph); }
+                    }
+                    const bool lng = ok && (e - s) > CONF_COOP;
+                    if (ok && !lng && s < e) {
                         const float half = c / 2.0f; // :95 (a fresh tensor: stays constant)
                         int good = 1;
                         float mx = 0.0f;
@@ -666,7 +678,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) vo
                             if (c < m2 / 2.0f) c = m2;
                         }
                     }
-                    cf[i] = c;
+                    unsigned long long pend = __ballot(lng);
+                    while (pend) {
+                        const int src = __builtin_ctzll(pend);
+                        pend &= pend - 1ull;
+                        // (wave-uniform values in scalar registers: the loops below are scalar loops, a value of lane j is one v_readlane)
+                        const int ci = __builtin_amdgcn_readlane(i, src), cph = __builtin_amdgcn_readlane(ph, src);
+                        const int cs = __builtin_amdgcn_readlane(s, src), ce = __builtin_amdgcn_readlane(e, src);
+                        float cc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), src));
+                        const float half = cc / 2.0f;
+                        int good = 1;
+                        float mx = 0.0f;
+                        for (int f0 = cs + 1; f0 < ce; f0 += 64) {
+                            const int f = f0 + lane;
+                            const float v = (f < ce) ? pr.at(ci, f, cph) : 0.0f;
+                            const int nv = min(64, ce - f0);
+                            for (int j = 0; j < nv; ++j) {
+                                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+                                mx = (f0 + j == cs + 1) ? vj : __builtin_fmaxf(mx, vj);
+                                if (vj > half || vj > 0.1f) { cc = cc + vj; good++; }
+                            }
+                        }
+                        if (good > 1) {
+                            cc = cc / (float)good;
+                            const float m2 = __builtin_fmaxf(cc, mx);
+                            if (cc < m2 / 2.0f) cc = m2;
+                        }
+                        if (lane == src) c = cc;
+                    }
+                    if (i < m) cf[i] = ok ? c : 0.0f;
                 }
             } else if ((size_t)m * 5 <= (size_t)a.cap_cells * 4) {
                 // exact serial replay with the write-through cells (rare: overlapping tuples of one phoneme); the staged

@@ -381,6 +381,39 @@ def test_confidences_parity(ora, gpu_device):
         assert (conf[b, :cnt[b]].view(np.int32) == c.view(np.int32)).all()
 
 
+def test_confidences_of_long_tuples(ora, gpu_device):
+    """Tuples of a hundred to several hundred frames (what the soft-boundary passes leave on soft posteriors): the
+    confidence pass takes them with the whole wave, 64 probes at a time, and adds in the reference's frame order
+    (utils.py:95-108).  Disjoint tuples of distinct starts: no aliasing replay.  Bit-identical to the oracle."""
+    from bournemouth_forced_aligner_amd import calculate_confidences_batch
+    rng = np.random.default_rng(19)
+    B, T, C = 12, 1400, 67
+    lp = rng.standard_normal((B, T, C)).astype(np.float32)
+    lp = lp - np.log(np.exp(lp.astype(np.float64)).sum(-1, keepdims=True)).astype(np.float32)
+    cap = 24
+    segs = np.zeros((B, cap, 4), np.int32)
+    cnt = np.zeros(B, np.int32)
+    for b in range(B):
+        t, n = int(rng.integers(0, 5)), 0
+        while n < cap:
+            ln = int(rng.choice([3, 40, 97, 98, 130, 200, 333, 64 + 65]))
+            if t + ln > T:
+                break
+            segs[b, n] = (int(rng.integers(0, C - 1)), t, t + ln, n)
+            t += ln + int(rng.integers(0, 3))
+            n += 1
+        cnt[b] = n
+    assert (segs[:, :, 2] - segs[:, :, 1]).max() > 300
+    lpd = torch.from_numpy(lp).to(gpu_device)
+    conf, status = calculate_confidences_batch(lpd, torch.from_numpy(segs), torch.from_numpy(cnt))
+    conf = conf.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for b in range(B):
+        rc, c, s, e = ora.confidences(lp[b], [tuple(r) for r in segs[b, :cnt[b]]])
+        assert rc == 0
+        assert (conf[b, :cnt[b]].view(np.int32) == c.view(np.int32)).all()
+
+
 @pytest.mark.parametrize("anchors", [10, 3, 5])
 def test_segmented_mode_parity(ora, gpu_device, anchors):
     """Targets with SIL and planted silences: silence detection, matching, per-segment DPs with
