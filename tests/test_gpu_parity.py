@@ -889,6 +889,35 @@ def test_soft_posteriors_real_text_chain(gpu_device):
         assert p["utterances"] >= B * 0.9 and p["mismatching_utterances"] == 0 and p["confidence_beyond_1e-4"] == 0, rec
 
 
+@pytest.mark.parametrize("peak", [9.0, 6.0, 3.0])
+def test_full_batch_layout_of_a_silence_anchored_call_every_utterance(gpu_device, peak):
+    """The launch layout of a FULL mixed-length silence-anchored batch (bench.py --config c5proxy), forced onto a call small
+    enough to compare every utterance (BFA_OPT_WIDE_ANY_MAX_BATCH = 8, so that 64 utterances are a "full batch"): fallbacks of
+    the window classes Rw <= 4 through k_mix, of Rw 6 / 8 through the exact-window class kernels, the slots no window fits in
+    the pieces' launch, k_dp5_any by class set (R 12 / 16, then R 4 / 6 / 8), all auxiliary kernels of a head on one lane.
+    Sharp (most utterances silence-anchored), middling and soft (none) posteriors; rows after coverage + soft boundaries bit-exact
+    and confidences within 1e-4 against the oracle's whole chain, every utterance, both heads."""
+    sys.path.insert(0, ROOT)
+    from tools import softness
+    from bournemouth_forced_aligner_amd import _lib
+    h = _lib.handle(0, 0)
+    _lib.check(_lib.lib().bfa_set_option(h, _lib.OPT_WIDE_ANY_MAX_BATCH, 8), h, "bfa_set_option")
+    try:
+        B = 64
+        a = _softness_args(batch=B)
+        a.parity = 2 * B
+        rec = softness.run_heads(a, "c5proxy", peak, gpu_device)
+    finally:
+        _lib.check(_lib.lib().bfa_set_option(h, _lib.OPT_WIDE_ANY_MAX_BATCH, 256), h, "bfa_set_option")
+    assert rec["status_ok"], rec
+    p = rec["parity"]
+    assert p["utterances"] >= B * 0.9 and p["mismatching_utterances"] == 0 and p["confidence_beyond_1e-4"] == 0, rec
+    if peak == 9.0:
+        assert min(rec["segmented_share"]) > 0.5, rec   # the anchored mode with its pieces
+    if peak == 3.0:
+        assert max(rec["segmented_share"]) == 0.0, rec  # every utterance a fallback
+
+
 def test_reference_post_dp_methods_on_the_mirror_class(ora, gpu_device):
     """PhonemeTimestampAligner.ensure_target_coverage / extend_soft_boundaries_func (core.py:462, 682) called directly, the way
     a user of the reference class may: host lists in, host lists out, against the oracle's restatement of both."""
