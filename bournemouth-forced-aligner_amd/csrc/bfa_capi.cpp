@@ -74,7 +74,7 @@ struct bfa_context {
     // a call leaves the call's window statistics in host-mapped memory (hist[slot], slot 0: C = 67, 1: C = 17); the next calls
     // read whatever has landed -- no synchronisation -- and switch: most fast windows gave up -> exact window at once
     // (XWIN_ROUTE); most exact reruns of a routed call ended above the sentinel -> fast windows again.
-    int wide_any_max = 256;       // BFA_OPT_WIDE_ANY_MAX_BATCH (< 0: the class kernels of rounds 2-5 for slots AND pieces)
+    int wide_any_max = 512;       // BFA_OPT_WIDE_ANY_MAX_BATCH (< 0: the class kernels of rounds 2-5 for slots AND pieces)
     int routing = 1;              // 0 never, 1 by history, 2 always exact-first
     int32_t *hist = nullptr;      // [2][8] host-mapped
     bool hist_tried = false;

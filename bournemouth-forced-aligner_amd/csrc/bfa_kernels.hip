@@ -264,7 +264,7 @@ static bool seg_wide_xwin()
     return on;
 }
 
-static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frames, int wide_any_max = 256)
+static CallPlan plan_call(int B, int C, int Smax, const DevParams &p, bool frames, int wide_any_max = 512)
 {
     // K1 classes that can occur: every CTC path has L <= 4*Smax+1; the caller may narrow this down
     const int Lmax = 4 * Smax + 1;

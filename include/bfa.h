@@ -275,7 +275,7 @@ int bfa_align_heads(bfa_handle h, const bfa_head *heads, int n_heads, int B, int
  *       synchronisation, possibly a call or two late) and, when one in 64 or more of a call's fast windows gave up (the
  *       rerun behind them is a second serial chain however few they are), hand every window item to the exact window at once
  *       -- until 99 in 100 of a routed call's items end above the sentinel again.  0: never (a fast attempt first, always), 2: always the exact window first.  Results are identical in all three.
- *   BFA_OPT_WIDE_ANY_MAX_BATCH  256 (default): the silence-anchored mode aligns the PIECES of the wide CTC-path classes (more
+ *   BFA_OPT_WIDE_ANY_MAX_BATCH  512 (default; 256 until the end of round 6, profiles/r06_layout_threshold_ab.txt): the silence-anchored mode aligns the PIECES of the wide CTC-path classes (more
  *       than 192 states) in one kernel with two consumer waves per piece, longest first; calls of at most this many utterances
  *       hand it their utterance slots (standard-mode fallbacks) as well instead of a kernel per class -- on an empty machine
  *       the launches are the cost, on a full one the registers of the widest class are.  < 0: a kernel per class and item

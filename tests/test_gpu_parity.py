@@ -908,7 +908,7 @@ def test_full_batch_layout_of_a_silence_anchored_call_every_utterance(gpu_device
         a.parity = 2 * B
         rec = softness.run_heads(a, "c5proxy", peak, gpu_device)
     finally:
-        _lib.check(_lib.lib().bfa_set_option(h, _lib.OPT_WIDE_ANY_MAX_BATCH, 256), h, "bfa_set_option")
+        _lib.check(_lib.lib().bfa_set_option(h, _lib.OPT_WIDE_ANY_MAX_BATCH, 512), h, "bfa_set_option")
     assert rec["status_ok"], rec
     p = rec["parity"]
     assert p["utterances"] >= B * 0.9 and p["mismatching_utterances"] == 0 and p["confidence_beyond_1e-4"] == 0, rec

@@ -28,6 +28,9 @@ al = PhonemeTimestampAligner(device="cuda:0", phoneme_id_to_group_id=gmap)
 ap, ag = AlignmentUtils(66, 0), AlignmentUtils(16, 0)
 BS = [int(v) for v in os.environ.get("BFA_BS", "1,4,16,64").split(",")]
 DEVICE_ONLY = bool(int(os.environ.get("BFA_DEVICE_ONLY", "0")))   # (kernel timelines: a few alignment calls, nothing else)
+if os.environ.get("BFA_WIDE_ANY_MAX"):   # (A/B of BFA_OPT_WIDE_ANY_MAX_BATCH, tools/r6_thresh.sh)
+    from bournemouth_forced_aligner_amd import _lib
+    _lib.check(_lib.lib().bfa_set_option(_lib.handle(0, 0), _lib.OPT_WIDE_ANY_MAX_BATCH, int(os.environ["BFA_WIDE_ANY_MAX"])), _lib.handle(0, 0), "bfa_set_option")
 for B in BS:
     xp, xg, tp, tg, Tl, Sl = synth_realtext_ragged(B, 300, 1870, tok_div, 3000 + B, dev, peak=peak, gpeak=max(1.0, peak - 2.0))
     Tn, Sn = Tl.numpy().astype(np.int64), Sl.numpy().astype(np.int64)
